@@ -1,0 +1,148 @@
+/*
+ * lbm_d2q9.h — C ABI of the MI355X-native D2Q9-BGK timestep path (liblbm_d2q9.so).
+ *
+ * The reference (ag14774/MPILattice-Boltzmann, one C file) has no plugin/FFI surface: its hot path
+ * is what main()'s loop calls between tic and toc (d2q9-bgk.c:278-398).  This header is the
+ * boundary a maintainer binds instead of those calls: plain pointers and sizes, no C++ or torch
+ * types.  Each entry point cites the reference lines it replaces (paths relative to the reference
+ * tree).  INTEGRATION.md shows the patch to the reference's main().
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; lbm_last_error() then returns a
+ *     message for the calling thread (HIP error text, or the reference's die() message for the
+ *     file parsers) — the reference itself reports nothing from these calls (d2q9-bgk.c:439,477,703);
+ *   - host arrays are caller-owned; device memory is library-owned (freed by lbm_destroy);
+ *   - cells cross the boundary in the reference's AoS layout: t_speed = float[9] per cell
+ *     (d2q9-bgk.c:95-98), row-major, x fastest, WITHOUT halo rows; obstacles as the reference's
+ *     int map (d2q9-bgk.c:162), 0 = fluid, non-zero = blocked;
+ *   - one context drives one partition (a block of consecutive rows, d2q9-bgk.c:834-862) on one
+ *     GPU from one host thread, like one MPI rank of the reference.
+ */
+#ifndef LBM_D2Q9_H
+#define LBM_D2Q9_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_ABI_VERSION 1
+#define LBM_NSPEEDS 9               /* d2q9-bgk.c:62 */
+
+/* Run constants as read from the parameter file: t_param (d2q9-bgk.c:79-90) minus free_cells_inv,
+ * which lbm_create derives from free_cells exactly as d2q9-bgk.c:950. */
+typedef struct lbm_params {
+  int nx, ny;                       /* GLOBAL grid size */
+  int max_iters;
+  int reynolds_dim;
+  float density, accel, omega;
+} lbm_params;
+
+typedef struct lbm_ctx lbm_ctx;     /* opaque: device state of one partition */
+
+/* lbm_create flags */
+#define LBM_FLAG_DEFAULT       0u
+#define LBM_FLAG_NT_STORES     1u   /* force non-temporal stores of the output grid (default: auto by size) */
+#define LBM_FLAG_NO_NT_STORES  2u   /* force plain stores */
+#define LBM_FLAG_KERNEL_LDS    4u   /* use the LDS-staged row kernel instead of the direct-load kernel */
+
+int         lbm_abi_version(void);
+const char* lbm_last_error(void);
+
+/* ---- host-side setup (no GPU needed) ------------------------------------------------------- */
+
+/* Replaces the parameter-file half of initialise(): d2q9-bgk.c:772-803.  On failure the message
+ * is the reference's die() text ("could not read param file: nx", ...). */
+int lbm_read_params(const char* paramfile, lbm_params* out);
+
+/* Replaces the obstacle-file half of initialise(): d2q9-bgk.c:917-953.  obstacles = ny*nx ints
+ * (zero-filled here); *free_cells = nx*ny minus the number of distinct blocked cells (:805,945-946). */
+int lbm_read_obstacles(const char* obstaclefile, int nx, int ny, int* obstacles, int* free_cells);
+
+/* Row decomposition rule of d2q9-bgk.c:834-862 (last rank keeps >= 3 rows). */
+int lbm_decompose(int ny, int size, int* ny_local, int* displs);
+
+/* ---- device state ---------------------------------------------------------------------------- */
+
+/* Replaces the allocation + initial-state part of initialise() (d2q9-bgk.c:865-911) for the rows
+ * [y0, y0+ny_local) of the global grid, on HIP device `device`.  obstacles_rows = this partition's
+ * ny_local*nx ints.  free_cells is the GLOBAL count.  ny_local == p->ny makes a self-contained
+ * periodic domain (the reference's 1-rank run, where top == bottom == self, :245-247).
+ * Requires nx % 4 == 0, ny_local >= 1 (>= 3 on the partition holding global row ny-2). */
+int lbm_create(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacles_rows,
+               int y0, int ny_local, int device, unsigned flags);
+int lbm_destroy(lbm_ctx* ctx);
+
+/* Replaces the whole timestep loop d2q9-bgk.c:315-394 for a self-contained domain
+ * (ny_local == ny): n_steps x { accelerate_flow (:442-478); timestep (:493-704); av_vels[tt]
+ * (:367); swap (:376-378) }.  av_vels (host, n_steps floats, may be NULL) receives one value per
+ * step.  May be called repeatedly; the state left behind is the reference's post-step state
+ * (collided, NOT yet accelerated), so reading it back at any point matches the reference. */
+int lbm_run(lbm_ctx* ctx, int n_steps, float* av_vels);
+
+/* Read / overwrite the partition's cells in the reference's AoS layout (ny_local*nx*9 floats). */
+int lbm_get_cells(lbm_ctx* ctx, float* cells_aos);
+int lbm_set_cells(lbm_ctx* ctx, const float* cells_aos);
+
+/* Device-side av_velocity (d2q9-bgk.c:716-751) over this partition's rows: *tot_u = sum over fluid
+ * cells of |u|, accumulated in double.  The caller applies free_cells_inv and sums partitions
+ * (d2q9-bgk.c:753-755). */
+int lbm_av_velocity_sum(lbm_ctx* ctx, double* tot_u);
+
+/* ---- split-phase stepping for row-partitioned runs (one context per GPU / rank) -------------
+ *
+ * Mirrors one iteration of d2q9-bgk.c:315-378 on one rank:
+ *     [caller starts the halo exchange: send buffers -> neighbours' recv buffers]   (:326-327)
+ *     lbm_step_interior(ctx, stream)      rows that need no halo                    (:345-350)
+ *     [caller waits for the exchange]                                                (:364)
+ *     lbm_step_boundary(ctx, stream)      first and last owned row + next step's send buffers (:365-366)
+ *     lbm_step_finish(ctx)                swap grids, advance the step counter      (:376-378)
+ * Only the three populations that cross each cut travel: one message per direction of
+ * lbm_halo_floats() floats (layout private to the library, identical on every rank of a run).
+ *   dir 0 = south = towards row y-1 (the reference's `top` rank, rank-1)
+ *   dir 1 = north = towards row y+1 (the reference's `bottom` rank, rank+1)
+ * stream: a hipStream_t passed as void*; NULL = the context's own stream.
+ * lbm_step_prepare() must be called once before the first step of a run of n_steps steps and
+ * after any lbm_set_cells: it applies the step-0 accelerate_flow and fills the send buffers. */
+size_t lbm_halo_floats(const lbm_ctx* ctx);
+void*  lbm_halo_send_ptr(lbm_ctx* ctx, int dir);      /* device pointers */
+void*  lbm_halo_recv_ptr(lbm_ctx* ctx, int dir);
+/* Optional: make the library use caller-owned DEVICE buffers (each lbm_halo_floats() floats, 16-byte
+ * aligned) for the four halo messages instead of its own — e.g. tensors of the framework that
+ * also owns the communicator.  Index as dir above.  Call before lbm_step_prepare. */
+int    lbm_bind_halo_buffers(lbm_ctx* ctx, void* send_south, void* send_north, void* recv_south, void* recv_north);
+int    lbm_step_prepare(lbm_ctx* ctx, int n_steps, void* stream);
+int    lbm_step_interior(lbm_ctx* ctx, void* stream);
+int    lbm_step_boundary(lbm_ctx* ctx, void* stream);
+int    lbm_step_finish(lbm_ctx* ctx, void* stream);
+/* After the last lbm_step_finish of a run: this partition's per-step tot_u sums (double, device
+ * resident until now) for the n_steps steps since lbm_step_prepare.  The caller reduces them over
+ * partitions (the reference's MPI_Reduce, d2q9-bgk.c:396) and scales by free_cells_inv. */
+int    lbm_step_collect(lbm_ctx* ctx, void* stream, double* tot_u_per_step, int n_steps);
+/* Device pointer of the same per-step sums (for a device-side all-reduce), valid after
+ * lbm_step_collect or a stream sync following the last lbm_step_finish. */
+void*  lbm_step_sums_device_ptr(lbm_ctx* ctx);
+
+/* Kernel/launch facts for the measurement harness: name of the dominant kernel as rocprofv3
+ * prints it, cells per launch, bytes of state in HBM. */
+int lbm_describe(const lbm_ctx* ctx, char* kernel_name, size_t len, long long* cells_per_launch,
+                 long long* state_bytes);
+
+/* ---- host-side epilogue (no GPU needed) ------------------------------------------------------ */
+
+/* av_velocity() for `rows` rows of AoS cells, reference order and precision (d2q9-bgk.c:716-751):
+ * returns tot_u (float accumulator). */
+float lbm_av_velocity_host(const lbm_params* p, const float* cells_aos, const int* obstacles, int rows);
+/* calc_reynolds() given av_velocity()'s value (d2q9-bgk.c:1005-1007). */
+float lbm_reynolds(const lbm_params* p, float av_velocity);
+/* write_values(): final_state.dat rows (d2q9-bgk.c:1054-1120; displ = global y of row 0; append as
+ * ranks > 0 do, :1057) and av_vels.dat (:1127-1139). */
+int lbm_write_final_state(const char* path, const lbm_params* p, const float* cells_aos,
+                          const int* obstacles, int rows, int displ, int append);
+int lbm_write_av_vels(const char* path, const float* av_vels, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

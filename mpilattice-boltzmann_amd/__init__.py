@@ -1,0 +1,21 @@
+"""MI355X-native D2Q9-BGK lattice-Boltzmann timestep path (drop-in for the hot path of
+ag14774/MPILattice-Boltzmann): hand-written gfx950 HIP kernels behind a C ABI
+(include/lbm_d2q9.h), a CLI shim with the reference's contract, and this Python host mirror.
+
+The directory name contains a hyphen; import it as `mpilattice_boltzmann_amd` (alias module at the
+repo root) or via importlib.
+"""
+from . import _capi, checker, decks
+from ._capi import EXPORTS, LIB_PATH, LbmError, load_library
+from .build import CLI as CLI_PATH
+from .build import build
+from .decks import Params, synthetic_obstacles, write_obstacles, write_synthetic_deck
+from .host import (NORTH, SOUTH, HaloExchange, Partition, Simulation, av_velocity_host, count_free_cells, decompose,
+                   read_obstacles, read_params, reynolds, run_partitioned, write_av_vels, write_final_state)
+
+__all__ = [
+    "EXPORTS", "LIB_PATH", "CLI_PATH", "LbmError", "load_library", "build", "Params", "synthetic_obstacles",
+    "write_obstacles", "write_synthetic_deck", "NORTH", "SOUTH", "HaloExchange", "Partition", "Simulation",
+    "av_velocity_host", "count_free_cells", "decompose", "read_obstacles", "read_params", "reynolds",
+    "run_partitioned", "write_av_vels", "write_final_state", "checker", "decks",
+]

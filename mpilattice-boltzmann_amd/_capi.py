@@ -1,0 +1,103 @@
+"""ctypes binding of include/lbm_d2q9.h (liblbm_d2q9.so).
+
+There is no CPU fallback: if the library is missing this module raises, and every device entry
+point raises LbmError with the library's message on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
+
+ABI_VERSION = 1
+NSPEEDS = 9
+
+FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS = 0, 1, 2, 4
+
+
+class LbmError(RuntimeError):
+    """A C-ABI call returned non-zero; str(e) is lbm_last_error()."""
+
+
+class CParams(C.Structure):
+    """struct lbm_params."""
+
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("max_iters", C.c_int), ("reynolds_dim", C.c_int),
+                ("density", C.c_float), ("accel", C.c_float), ("omega", C.c_float)]
+
+
+_P = C.POINTER
+_ctx = C.c_void_p
+_SIGNATURES = {
+    "lbm_abi_version": (C.c_int, []),
+    "lbm_last_error": (C.c_char_p, []),
+    "lbm_read_params": (C.c_int, [C.c_char_p, _P(CParams)]),
+    "lbm_read_obstacles": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "lbm_decompose": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "lbm_create": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "lbm_destroy": (C.c_int, [_ctx]),
+    "lbm_run": (C.c_int, [_ctx, C.c_int, _P(C.c_float)]),
+    "lbm_get_cells": (C.c_int, [_ctx, _P(C.c_float)]),
+    "lbm_set_cells": (C.c_int, [_ctx, _P(C.c_float)]),
+    "lbm_av_velocity_sum": (C.c_int, [_ctx, _P(C.c_double)]),
+    "lbm_halo_floats": (C.c_size_t, [_ctx]),
+    "lbm_halo_send_ptr": (C.c_void_p, [_ctx, C.c_int]),
+    "lbm_halo_recv_ptr": (C.c_void_p, [_ctx, C.c_int]),
+    "lbm_bind_halo_buffers": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lbm_step_prepare": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "lbm_step_interior": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_step_boundary": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_step_finish": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_step_collect": (C.c_int, [_ctx, C.c_void_p, _P(C.c_double), C.c_int]),
+    "lbm_step_sums_device_ptr": (C.c_void_p, [_ctx]),
+    "lbm_describe": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_longlong), _P(C.c_longlong)]),
+    "lbm_av_velocity_host": (C.c_float, [_P(CParams), _P(C.c_float), _P(C.c_int), C.c_int]),
+    "lbm_reynolds": (C.c_float, [_P(CParams), C.c_float]),
+    "lbm_write_final_state": (C.c_int, [C.c_char_p, _P(CParams), _P(C.c_float), _P(C.c_int), C.c_int, C.c_int, C.c_int]),
+    "lbm_write_av_vels": (C.c_int, [C.c_char_p, _P(C.c_float), C.c_int]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load liblbm_d2q9.so from the package tree and type every export.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is the only implementation of the timestep path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.lbm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"liblbm_d2q9.so ABI {lib.lbm_abi_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise LbmError(load_library().lbm_last_error().decode(errors="replace"))
+
+
+def as_float_ptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_P(C.c_float))
+
+
+def as_int_ptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_P(C.c_int))
+
+
+def as_double_ptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_P(C.c_double))

@@ -1,0 +1,58 @@
+"""In-tree build of the native half: liblbm_d2q9.so (HIP kernels + C ABI) and the d2q9-bgk CLI shim.
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the build container; the
+outputs (lib/, bin/) are git-ignored but travel to the GPU box with the tree.  gfx950 only.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib", "liblbm_d2q9.so")
+CLI = os.path.join(PKG, "bin", "d2q9-bgk")
+
+# -ffp-contract=off: keep the reference's unfused float arithmetic (bit parity with gcc -std=c99).
+COMMON = ["-O3", "-ffp-contract=off", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP path cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
+    """Compile the shared library and the CLI if missing or older than their sources."""
+    hipcc = _hipcc()
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    headers = [os.path.join(ROOT, "include", "lbm_d2q9.h"), os.path.join(CSRC, "lbm_internal.h"), os.path.abspath(__file__)]
+    lib_src = [os.path.join(CSRC, "lbm_kernels.hip"), os.path.join(CSRC, "lbm_host.cpp")]
+    if force or _stale(LIB, lib_src + headers):
+        cmd = [hipcc, "--offload-arch=gfx950", *COMMON, "-fPIC", "-shared", *lib_src, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    cli_src = [os.path.join(CSRC, "d2q9_bgk_main.cpp")]
+    if force or _stale(CLI, cli_src + headers + [LIB]):
+        cmd = [hipcc, *COMMON, *cli_src, "-L", os.path.dirname(LIB), "-llbm_d2q9", "-Wl,-rpath,$ORIGIN/../lib", "-o", CLI]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return {"lib": LIB, "cli": CLI}
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,169 @@
+// lbm_host.cpp — host-only half of the C ABI (include/lbm_d2q9.h): the reference's input parsers,
+// row decomposition, end-of-run reductions and output writers.  No HIP calls in this file; it is
+// what the CLI shim and the Python host use around the device path, and it is exercised on
+// GPU-less machines by the CPU test suite.  Reference lines are relative to the reference tree.
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lbm_d2q9.h"
+#include "lbm_internal.h"
+
+namespace {
+thread_local std::string g_error;
+}
+
+namespace lbm_internal {
+void set_error(const std::string& msg) { g_error = msg; }
+}  // namespace lbm_internal
+
+using lbm_internal::set_error;
+
+extern "C" {
+
+int lbm_abi_version(void) { return LBM_ABI_VERSION; }
+const char* lbm_last_error(void) { return g_error.c_str(); }
+
+// d2q9-bgk.c:772-803 — same token order, same conversion (fscanf %d / %f), same messages.
+int lbm_read_params(const char* paramfile, lbm_params* out)
+{
+  if (!paramfile || !out) { set_error("lbm_read_params: null argument"); return 1; }
+  std::FILE* fp = std::fopen(paramfile, "r");
+  if (!fp) { set_error(std::string("could not open input parameter file: ") + paramfile); return 1; }   // :776
+  struct Field { const char* name; const char* fmt; void* dst; };
+  const Field fields[7] = {
+      {"nx", "%d\n", &out->nx},           {"ny", "%d\n", &out->ny},
+      {"maxIters", "%d\n", &out->max_iters}, {"reynolds_dim", "%d\n", &out->reynolds_dim},
+      {"density", "%f\n", &out->density}, {"accel", "%f\n", &out->accel},
+      {"omega", "%f\n", &out->omega}};
+  for (const Field& f : fields) {
+    if (std::fscanf(fp, f.fmt, f.dst) != 1) {                                                             // :781-800
+      std::fclose(fp);
+      set_error(std::string("could not read param file: ") + f.name);
+      return 1;
+    }
+  }
+  std::fclose(fp);
+  return 0;
+}
+
+// d2q9-bgk.c:917-953.
+int lbm_read_obstacles(const char* obstaclefile, int nx, int ny, int* obstacles, int* free_cells)
+{
+  if (!obstaclefile || !obstacles || !free_cells || nx <= 0 || ny <= 0) { set_error("lbm_read_obstacles: bad argument"); return 1; }
+  const size_t n = static_cast<size_t>(nx) * static_cast<size_t>(ny);
+  std::memset(obstacles, 0, sizeof(int) * n);                                                             // :918-922
+  int nfree = nx * ny;                                                                                    // :805
+  std::FILE* fp = std::fopen(obstaclefile, "r");
+  if (!fp) { set_error(std::string("could not open input obstacles file: ") + obstaclefile); return 1; }  // :928
+  int xx = 0, yy = 0, blocked = 0, got = 0;
+  while ((got = std::fscanf(fp, "%d %d %d\n", &xx, &yy, &blocked)) != EOF) {                              // :933
+    const char* bad = nullptr;
+    if (got != 3) bad = "expected 3 values per line in obstacle file";                                    // :936
+    else if (xx < 0 || xx > nx - 1) bad = "obstacle x-coord out of range";                                // :938
+    else if (yy < 0 || yy > ny - 1) bad = "obstacle y-coord out of range";                                // :940
+    else if (blocked != 1) bad = "obstacle blocked value should be 1";                                    // :942
+    if (bad) { std::fclose(fp); set_error(bad); return 1; }
+    int& cell = obstacles[static_cast<size_t>(yy) * nx + xx];
+    if (cell == 0) --nfree;                                                                               // :945-946
+    cell = blocked;                                                                                       // :947
+  }
+  std::fclose(fp);
+  *free_cells = nfree;
+  return 0;
+}
+
+// d2q9-bgk.c:834-862.
+int lbm_decompose(int ny, int size, int* ny_local, int* displs)
+{
+  if (ny <= 0 || size <= 0 || !ny_local || !displs) { set_error("lbm_decompose: bad argument"); return 1; }
+  int rows = ny / size, spare = ny % size;
+  int last_gets_one = 0, second_last_gives_one = 0;
+  if (rows < 3) {                 // the last rank must own >= 3 rows (:848-849)
+    last_gets_one = 1;
+    if (spare) --spare; else second_last_gives_one = 1;   // :840-847
+  }
+  int at = 0;
+  for (int r = 0; r < size; ++r) {
+    int n = rows;
+    if (r == size - 2) n -= second_last_gives_one;
+    if (r == size - 1) n += last_gets_one;
+    if (r < spare) ++n;
+    ny_local[r] = n;
+    displs[r] = at;
+    at += n;
+  }
+  return 0;
+}
+
+// d2q9-bgk.c:716-751 (without the MPI_Reduce): float accumulator, double sqrt.
+float lbm_av_velocity_host(const lbm_params* p, const float* cells, const int* obstacles, int rows)
+{
+  float tot_u = 0.0f;
+  const size_t n = static_cast<size_t>(rows) * static_cast<size_t>(p->nx);
+  for (size_t c = 0; c < n; ++c) {
+    if (obstacles[c]) continue;                                                 // :721
+    const float* f = cells + c * LBM_NSPEEDS;
+    float rho = 0.0f;
+    for (int k = 0; k < LBM_NSPEEDS; ++k) rho += f[k];                          // :724-729
+    const float ux = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;         // :732-738
+    const float uy = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;         // :740-746
+    tot_u += std::sqrt(static_cast<double>((ux * ux) + (uy * uy)));            // :748
+  }
+  return tot_u;
+}
+
+// d2q9-bgk.c:1005-1007.
+float lbm_reynolds(const lbm_params* p, float av_velocity)
+{
+  const float viscosity = 1.0f / 6.0f * (2.0f / p->omega - 1.0f);
+  return av_velocity * p->reynolds_dim / viscosity;
+}
+
+// d2q9-bgk.c:1054-1120.
+int lbm_write_final_state(const char* path, const lbm_params* p, const float* cells, const int* obstacles,
+                          int rows, int displ, int append)
+{
+  std::FILE* fp = std::fopen(path, append ? "a" : "w");                        // :1054-1057
+  if (!fp) { set_error("could not open file output file"); return 1; }         // :1061
+  std::vector<char> buf(4u << 20);
+  std::setvbuf(fp, buf.data(), _IOFBF, buf.size());
+  const float c_sq = 1.0f / 3.0f;                                              // :1040
+  for (int y = 0; y < rows; ++y) {
+    for (int x = 0; x < p->nx; ++x) {
+      const size_t c = static_cast<size_t>(y) * p->nx + x;
+      float u_x, u_y, u, pressure;
+      if (obstacles[c]) {                                                      // :1076-1080
+        u_x = u_y = u = 0.0f;
+        pressure = p->density * c_sq;
+      } else {
+        const float* f = cells + c * LBM_NSPEEDS;
+        float rho = 0.0f;
+        for (int k = 0; k < LBM_NSPEEDS; ++k) rho += f[k];                     // :1084-1090
+        u_x = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;               // :1093-1099
+        u_y = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;               // :1101-1107
+        u = static_cast<float>(std::sqrt(static_cast<double>((u_x * u_x) + (u_y * u_y))));   // :1109
+        pressure = rho * c_sq;                                                 // :1111
+      }
+      std::fprintf(fp, "%d %d %.12E %.12E %.12E %.12E %d\n", x, y + displ, u_x, u_y, u, pressure, obstacles[c]);   // :1115
+    }
+  }
+  std::fclose(fp);
+  return 0;
+}
+
+// d2q9-bgk.c:1127-1139.
+int lbm_write_av_vels(const char* path, const float* av_vels, int n)
+{
+  std::FILE* fp = std::fopen(path, "w");
+  if (!fp) { set_error("could not open file output file"); return 1; }         // :1131
+  for (int i = 0; i < n; ++i) std::fprintf(fp, "%d:\t%.12E\n", i, av_vels[i]); // :1136
+  std::fclose(fp);
+  return 0;
+}
+
+}  // extern "C"

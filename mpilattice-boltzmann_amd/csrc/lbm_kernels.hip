@@ -1,0 +1,821 @@
+// lbm_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels + device half of the C ABI
+// (include/lbm_d2q9.h) for the D2Q9-BGK timestep path of ag14774/MPILattice-Boltzmann.
+//
+// What one launch of lbm_step_* does (reference lines, relative to the reference tree):
+//   pull-stream            d2q9-bgk.c:526-538      9 populations from the 3x3 neighbourhood
+//   moments + equilibrium  d2q9-bgk.c:546-646
+//   BGK relaxation         d2q9-bgk.c:658-666      fluid cells
+//   bounce-back            d2q9-bgk.c:687-695      obstacle cells
+//   sum |u|                d2q9-bgk.c:667,684      -> per-block partial, double
+//   accelerate_flow        d2q9-bgk.c:442-478      fused as an EPILOGUE on global row ny-2: the row is
+//                                                  written already accelerated for the next step
+//   av_vels[tt-1]          d2q9-bgk.c:367          block 0 folds the previous launch's partials
+//
+// Layout in HBM: struct-of-arrays, 9 planes of ny_local*nx floats (plane stride padded, see
+// plane_stride_floats()), two grids (source / destination, swapped per step like :376-378), the
+// obstacle map as a bitfield (1 bit per cell).  Every population value is consumed by exactly one
+// cell per step, so the kernel is a pure stream: 9 x 16-byte loads + 9 x 16-byte stores per lane
+// (4 cells per lane), no MFMA, bounded by HBM bandwidth.
+//
+// Arithmetic is written in the reference's operation order and this file is compiled with
+// -ffp-contract=off, so the post-step populations are BIT-IDENTICAL to the reference's
+// (gcc -std=c99 never fuses either); 1.0f/x and sqrt are correctly rounded (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  Only the summation order of sum|u| differs
+// (tree in double instead of a serial float accumulator).
+//
+// gfx950 only: 64-wide wavefronts are assumed throughout (wave reductions step through 32..1).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lbm_d2q9.h"
+#include "lbm_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 wavefronts
+constexpr int kCellsPerLane = 4;     // one 16-byte access per population per lane
+constexpr int kHaloGuard = 4;        // floats of guard on each side of a halo-buffer row
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
+
+struct StepArgs {
+  const float* src;            // source grid, plane 0 row 0
+  float* dst;                  // destination grid
+  const uint32_t* mask;        // obstacle bitfield, bit c of the partition-local cell index
+  size_t ps;                   // plane stride in floats
+  int nx, nyl;                 // row length, rows owned by this partition
+  int quad_begin, quad_end;    // 4-cell groups [begin,end) of the partition handled by this launch
+  int quad_begin2, quad_end2;  // optional second range (boundary launch: last row), empty if begin2>=end2
+  int iters;                   // 1024-cell chunks per block
+  // sources outside the partition (row-partitioned runs); nullptr = periodic wrap inside the plane
+  const float* south_halo;     // populations 2,5,6 of the row below row 0   [3][nxp], data at +kHaloGuard
+  const float* north_halo;     // populations 4,7,8 of the row above row nyl-1
+  float* send_south;           // row 0's populations 4,7,8 for the southern neighbour (next step)
+  float* send_north;           // row nyl-1's populations 2,5,6 for the northern neighbour
+  int nxp;                     // halo-buffer row pitch = nx + 2*kHaloGuard
+  float omega;
+  float accel_w1, accel_w2;    // d2q9-bgk.c:445-446
+  int accel_row;               // local row that is global row ny-2, or -1: epilogue accelerate for the NEXT step
+  double* partials_out;        // this launch's per-block sums
+  const double* prev_partials; // previous step's per-block sums, folded by block 0 of this launch
+  int n_prev;
+  double* sums;                // per-step totals of this run
+  int* counter;                // index of the next entry of sums
+};
+
+__device__ __forceinline__ f4 load4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ f4 load4u(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+
+template <bool NT>
+__device__ __forceinline__ void store4(float* p, f4 v)
+{
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+  else *reinterpret_cast<f4*>(p) = v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Deterministic block sum (fixed tree): every thread gets the total.
+__device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 doubles */)
+{
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[wave] = v;
+  __syncthreads();
+  double t = lds[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / 64; ++w) t += lds[w];
+  return t;
+}
+
+// One cell: moments, equilibrium, relaxation in the reference's operation order (d2q9-bgk.c:546-666).
+// t[] = streamed-in populations, o[] = relaxed populations; returns sqrt(m^2)/rho in double (:667).
+__device__ __forceinline__ double relax_cell(const float (&t)[9], float omega, float (&o)[9])
+{
+  const float csq_inv = 3.0f;                                   // :497
+  const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;   // :499-501
+  float rho = t[0];                                             // :546-554
+  rho += t[1]; rho += t[2]; rho += t[3]; rho += t[4];
+  rho += t[5]; rho += t[6]; rho += t[7]; rho += t[8];
+  const float rinv = 1.0f / rho;                                // :561
+  float mx = t[1] + t[5];                                       // :570-574
+  mx += t[8]; mx -= t[3]; mx -= t[6]; mx -= t[7];
+  float my = t[2] + t[5];                                       // :576-580
+  my += t[6]; my -= t[4]; my -= t[7]; my -= t[8];
+  const float msq = mx * mx + my * my;                          // :589
+  float e[9];
+  e[1] = mx;       e[2] = my;        e[3] = -mx;       e[4] = -my;        // :596-599
+  e[5] = mx + my;  e[6] = -mx + my;  e[7] = -mx - my;  e[8] = mx - my;    // :600-603
+  const float h = 0.5f * rinv * csq_inv;                        // "0.5f*densinv*ic_sq" of :638-646
+  const float q0 = w0 * (rho - h * msq);                        // :638
+  o[0] = t[0] + omega * (q0 - t[0]);                            // :658
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const float a = e[k] * csq_inv;                             // :610-617
+    const float b = a * e[k];                                   // :624-631
+    const float wk = (k < 5) ? w1 : w2;
+    const float q = wk * (rho + a + h * (b - msq));             // :639-646
+    o[k] = t[k] + omega * (q - t[k]);                           // :659-666
+  }
+  return sqrt(static_cast<double>(msq)) * static_cast<double>(rinv);   // :667
+}
+
+// Processes the 4 cells starting at partition-local cell index c (c % 4 == 0, nx % 4 == 0, so
+// the four share a row).  Returns their sum|u| contribution.
+template <bool NT>
+__device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
+{
+  const int c = quad * kCellsPerLane;
+  const int y = c / a.nx;
+  const int x0 = c - y * a.nx;
+  const size_t ps = a.ps;
+  const int nx = a.nx;
+
+  // row bases of the three source rows, per population group
+  const float* here = a.src + static_cast<size_t>(y) * nx;            // populations 0,1,3: + k*ps
+  const float *s2, *s5, *s6, *n4, *n7, *n8;
+  if (y > 0 || a.south_halo == nullptr) {
+    const int ys = (y > 0) ? y - 1 : a.nyl - 1;                        // periodic wrap (:245-247 with one rank)
+    const float* r = a.src + static_cast<size_t>(ys) * nx;
+    s2 = r + 2 * ps; s5 = r + 5 * ps; s6 = r + 6 * ps;
+  } else {
+    const float* r = a.south_halo + kHaloGuard;
+    s2 = r; s5 = r + a.nxp; s6 = r + 2 * a.nxp;
+  }
+  if (y < a.nyl - 1 || a.north_halo == nullptr) {
+    const int yn = (y < a.nyl - 1) ? y + 1 : 0;
+    const float* r = a.src + static_cast<size_t>(yn) * nx;
+    n4 = r + 4 * ps; n7 = r + 7 * ps; n8 = r + 8 * ps;
+  } else {
+    const float* r = a.north_halo + kHaloGuard;
+    n4 = r; n7 = r + a.nxp; n8 = r + 2 * a.nxp;
+  }
+
+  // pull (d2q9-bgk.c:530-538): aligned for x, dword-shifted for x-1 / x+1
+  f4 p[9];
+  p[0] = load4(here + x0);
+  p[2] = load4(s2 + x0);
+  p[4] = load4(n4 + x0);
+  p[1] = load4u(here + ps + x0 - 1);
+  p[5] = load4u(s5 + x0 - 1);
+  p[8] = load4u(n8 + x0 - 1);
+  p[3] = load4u(here + 3 * ps + x0 + 1);
+  p[6] = load4u(s6 + x0 + 1);
+  p[7] = load4u(n7 + x0 + 1);
+  const uint32_t mword = a.mask[c >> 5];
+  if (x0 == 0) {                       // x_w wraps to nx-1 (:529)
+    p[1].x = here[ps + nx - 1];
+    p[5].x = s5[nx - 1];
+    p[8].x = n8[nx - 1];
+  }
+  if (x0 == nx - kCellsPerLane) {      // x_e wraps to 0 (:527-528)
+    p[3].w = here[3 * ps];
+    p[6].w = s6[0];
+    p[7].w = n7[0];
+  }
+  const uint32_t mbits = (mword >> (c & 31)) & 0xFu;
+
+  f4 out[9];
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < kCellsPerLane; ++j) {
+    float t[9], o[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = p[k][j];
+    const double term = relax_cell(t, a.omega, o);
+    const bool blocked = (mbits >> j) & 1u;
+    // bounce-back (d2q9-bgk.c:687-695): out[opposite(k)] = t[k]
+    out[0][j] = blocked ? t[0] : o[0];
+    out[1][j] = blocked ? t[3] : o[1];
+    out[2][j] = blocked ? t[4] : o[2];
+    out[3][j] = blocked ? t[1] : o[3];
+    out[4][j] = blocked ? t[2] : o[4];
+    out[5][j] = blocked ? t[7] : o[5];
+    out[6][j] = blocked ? t[8] : o[6];
+    out[7][j] = blocked ? t[5] : o[7];
+    out[8][j] = blocked ? t[6] : o[8];
+    acc += blocked ? 0.0 : term;
+  }
+
+  // accelerate_flow for the NEXT step, applied to the freshly written row ny-2 (d2q9-bgk.c:457-469)
+  if (y == a.accel_row) {
+#pragma unroll
+    for (int j = 0; j < kCellsPerLane; ++j) {
+      const bool blocked = (mbits >> j) & 1u;
+      if (!blocked && out[3][j] - a.accel_w1 > 0.0f && out[6][j] - a.accel_w2 > 0.0f &&
+          out[7][j] - a.accel_w2 > 0.0f) {
+        out[1][j] += a.accel_w1; out[5][j] += a.accel_w2; out[8][j] += a.accel_w2;
+        out[3][j] -= a.accel_w1; out[6][j] -= a.accel_w2; out[7][j] -= a.accel_w2;
+      }
+    }
+  }
+
+  float* d = a.dst + c;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) store4<NT>(d + k * ps, out[k]);
+
+  // next step's outgoing halo rows (row-partitioned runs only)
+  if (a.send_south != nullptr && y == 0) {
+    float* s = a.send_south + kHaloGuard + x0;
+    store4<false>(s, out[4]); store4<false>(s + a.nxp, out[7]); store4<false>(s + 2 * a.nxp, out[8]);
+  }
+  if (a.send_north != nullptr && y == a.nyl - 1) {
+    float* s = a.send_north + kHaloGuard + x0;
+    store4<false>(s, out[2]); store4<false>(s + a.nxp, out[5]); store4<false>(s + 2 * a.nxp, out[6]);
+  }
+  return acc;
+}
+
+// The fused streaming-pull step.  Grid: ceil(#quads / (256*iters)) blocks of 256 lanes; block b
+// owns `iters` consecutive 1024-cell chunks.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
+{
+  __shared__ double red[kBlock / 64];
+
+  // block 0: fold the previous step's per-block sums into sums[counter++] (d2q9-bgk.c:367)
+  if (blockIdx.x == 0 && a.n_prev > 0) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s += a.prev_partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+      const int t = *a.counter;
+      a.sums[t] = s;
+      *a.counter = t + 1;
+    }
+  }
+
+  double acc = 0.0;
+  const int n1 = a.quad_end - a.quad_begin;
+  const int n2 = a.quad_end2 > a.quad_begin2 ? a.quad_end2 - a.quad_begin2 : 0;
+  const int base = blockIdx.x * a.iters * kBlock + threadIdx.x;
+  for (int i = 0; i < a.iters; ++i) {
+    const int r = base + i * kBlock;
+    if (r < n1 + n2) acc += step_quad<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) a.partials_out[blockIdx.x] = acc;
+}
+
+// Folds the last step's partials after the loop.
+__global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, double* sums, int* counter)
+{
+  __shared__ double red[kBlock / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += partials[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const int t = *counter;
+    sums[t] = s;
+    *counter = t + 1;
+  }
+}
+
+// accelerate_flow (d2q9-bgk.c:442-478) in place on one row: only needed before the first step of a run.
+__global__ void lbm_accelerate_kernel(float* grid, size_t ps, const uint32_t* mask, int nx, int row, float w1, float w2)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const size_t c = static_cast<size_t>(row) * nx + x;
+  if ((mask[c >> 5] >> (c & 31)) & 1u) return;
+  float* f = grid + c;
+  const float f3 = f[3 * ps], f6 = f[6 * ps], f7 = f[7 * ps];
+  if (f3 - w1 > 0.0f && f6 - w2 > 0.0f && f7 - w2 > 0.0f) {
+    f[1 * ps] += w1; f[5 * ps] += w2; f[8 * ps] += w2;
+    f[3 * ps] = f3 - w1; f[6 * ps] = f6 - w2; f[7 * ps] = f7 - w2;
+  }
+}
+
+// Initial state (d2q9-bgk.c:880-902).
+__global__ void lbm_init_kernel(float* grid, size_t ps, size_t ncells, float w0, float w1, float w2)
+{
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= ncells) return;
+  grid[i] = w0;
+#pragma unroll
+  for (int k = 1; k < 5; ++k) grid[k * ps + i] = w1;
+#pragma unroll
+  for (int k = 5; k < 9; ++k) grid[k * ps + i] = w2;
+}
+
+// AoS (reference t_speed) <-> SoA planes.
+__global__ void lbm_aos_to_soa_kernel(const float* aos, float* grid, size_t ps, size_t ncells)
+{
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= ncells * 9) return;
+  const size_t c = i / 9;
+  const int k = static_cast<int>(i - c * 9);
+  grid[k * ps + c] = aos[i];
+}
+
+__global__ void lbm_soa_to_aos_kernel(const float* grid, float* aos, size_t ps, size_t ncells)
+{
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= ncells * 9) return;
+  const size_t c = i / 9;
+  const int k = static_cast<int>(i - c * 9);
+  aos[i] = grid[k * ps + c];
+}
+
+// Outgoing halo rows of the CURRENT grid (before the first step of a row-partitioned run).
+__global__ void lbm_pack_halo_kernel(const float* grid, size_t ps, int nx, int nyl, int nxp, float* send_south, float* send_north)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const float* first = grid + x;
+  const float* last = grid + static_cast<size_t>(nyl - 1) * nx + x;
+  float* ss = send_south + kHaloGuard + x;
+  float* sn = send_north + kHaloGuard + x;
+  ss[0] = first[4 * ps]; ss[nxp] = first[7 * ps]; ss[2 * nxp] = first[8 * ps];
+  sn[0] = last[2 * ps];  sn[nxp] = last[5 * ps];  sn[2 * nxp] = last[6 * ps];
+}
+
+// av_velocity (d2q9-bgk.c:716-751): per-cell float arithmetic as the reference, double accumulation.
+__global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t ncells, double* partials)
+{
+  __shared__ double red[kBlock / 64];
+  double acc = 0.0;
+  for (size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; c < ncells; c += static_cast<size_t>(gridDim.x) * kBlock) {
+    if ((mask[c >> 5] >> (c & 31)) & 1u) continue;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = grid[k * ps + c];
+    float rho = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rho += f[k];                                   // :724-729
+    const float ux = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;        // :732-738
+    const float uy = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;        // :740-746
+    acc += sqrt(static_cast<double>((ux * ux) + (uy * uy)));                   // :748
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the device ABI
+// ------------------------------------------------------------------------------------------------
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      lbm_internal::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return 1;                                                                              \
+    }                                                                                        \
+  } while (0)
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// Plane stride: rows*nx floats + guard for the dword-shifted loads at both ends, rounded to 256 B,
+// then skewed by an odd number of 256-B units so the 9 planes (and the two grids) do not all start
+// on the same HBM channel when rows*nx is a large power of two.
+size_t plane_stride_floats(size_t ncells)
+{
+  size_t s = round_up(ncells + 64, 64);
+  if ((s / 64) % 2 == 0) s += 64;
+  if (ncells >= (1u << 20)) s += 64 * 34;   // ~8.5 KiB skew between planes for large grids
+  return s;
+}
+
+}  // namespace
+
+struct lbm_ctx {
+  lbm_params p{};
+  int free_cells = 0;
+  float free_cells_inv = 0.f;
+  int y0 = 0, nyl = 0, device = 0;
+  unsigned flags = 0;
+  bool self_periodic = true;
+  int accel_row = -1;
+  bool nt_stores = false;
+  size_t ncells = 0, ps = 0, grid_floats = 0;
+  float* grid_alloc[2] = {nullptr, nullptr};
+  float* grid[2] = {nullptr, nullptr};       // plane 0 row 0 (after the front guard)
+  int cur = 0;
+  uint32_t* mask = nullptr;
+  int nxp = 0;
+  float* halo_alloc = nullptr;
+  float* send[2] = {nullptr, nullptr};
+  float* recv[2] = {nullptr, nullptr};
+  double* partials[2] = {nullptr, nullptr};
+  int partials_cap = 0;
+  int n_part_interior = 0, n_part_boundary = 0, n_part_full = 0;
+  int iters_full = 1, iters_interior = 1;
+  double* sums = nullptr;
+  int sums_cap = 0;
+  int* counter = nullptr;
+  hipStream_t stream = nullptr;
+  // run state (split-phase and lbm_run)
+  int run_steps = 0, run_done = 0;
+  int parity = 0;            // partials buffer written by the current step
+  int n_prev = 0;            // partial count of the previous step (0 = nothing to fold)
+  float accel_w1 = 0.f, accel_w2 = 0.f;
+};
+
+namespace {
+
+int pick_iters(long long quads)
+{
+  // keep the grid at <= ~4096 blocks (16 per CU): fewer, longer blocks and a short partial vector
+  long long chunks = (quads + kBlock - 1) / kBlock;
+  int iters = 1;
+  while (chunks / iters > 4096 && iters < 64) iters *= 2;
+  return iters;
+}
+
+int blocks_for(long long quads, int iters)
+{
+  const long long per_block = static_cast<long long>(kBlock) * iters;
+  return static_cast<int>((quads + per_block - 1) / per_block);
+}
+
+hipStream_t pick_stream(lbm_ctx* c, void* stream) { return stream ? static_cast<hipStream_t>(stream) : c->stream; }
+
+int ensure_sums(lbm_ctx* c, int n)
+{
+  if (n <= c->sums_cap) return 0;
+  if (c->sums) HIP_TRY(hipFree(c->sums));
+  c->sums = nullptr;
+  c->sums_cap = 0;
+  HIP_TRY(hipMalloc(&c->sums, sizeof(double) * static_cast<size_t>(n)));
+  c->sums_cap = n;
+  return 0;
+}
+
+StepArgs base_args(lbm_ctx* c, bool accel_next)
+{
+  StepArgs a{};
+  a.src = c->grid[c->cur];
+  a.dst = c->grid[c->cur ^ 1];
+  a.mask = c->mask;
+  a.ps = c->ps;
+  a.nx = c->p.nx;
+  a.nyl = c->nyl;
+  a.nxp = c->nxp;
+  a.omega = c->p.omega;
+  a.accel_w1 = c->accel_w1;
+  a.accel_w2 = c->accel_w2;
+  a.accel_row = accel_next ? c->accel_row : -1;
+  a.sums = c->sums;
+  a.counter = c->counter;
+  return a;
+}
+
+void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
+{
+  if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL(lbm_step_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, a);
+}
+
+int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
+{
+  if (ensure_sums(c, n_steps)) return 1;
+  HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(int), s));
+  c->run_steps = n_steps;
+  c->run_done = 0;
+  c->n_prev = 0;
+  c->parity = 0;
+  if (c->accel_row >= 0 && n_steps > 0) {
+    // accelerate_flow of step 0 (d2q9-bgk.c:345-348); later steps get it from the kernel epilogue
+    const int nx = c->p.nx;
+    hipLaunchKernelGGL(lbm_accelerate_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps,
+                       c->mask, nx, c->accel_row, c->accel_w1, c->accel_w2);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows, int y0,
+               int ny_local, int device, unsigned flags)
+{
+  if (!out || !p || !obstacles_rows) { lbm_internal::set_error("lbm_create: null argument"); return 1; }
+  *out = nullptr;
+  if (p->nx < 4 || p->nx % 4 != 0) { lbm_internal::set_error("lbm_create: nx must be a positive multiple of 4"); return 1; }
+  if (p->ny < 3) { lbm_internal::set_error("lbm_create: ny must be >= 3 (accelerate_flow works on row ny-2, d2q9-bgk.c:449)"); return 1; }
+  if (ny_local < 1 || y0 < 0 || y0 + ny_local > p->ny) { lbm_internal::set_error("lbm_create: partition rows out of range"); return 1; }
+  if (free_cells <= 0) { lbm_internal::set_error("lbm_create: free_cells must be positive"); return 1; }
+  const bool self_periodic = (ny_local == p->ny);
+  const int accel_global = p->ny - 2;
+  int accel_row = -1;
+  if (accel_global >= y0 && accel_global < y0 + ny_local) accel_row = accel_global - y0;
+  if (!self_periodic && accel_row >= 0 && (accel_row == 0 || accel_row == ny_local - 1)) {
+    lbm_internal::set_error("lbm_create: the partition holding row ny-2 needs >= 3 rows (d2q9-bgk.c:848-849)");
+    return 1;
+  }
+  if (static_cast<long long>(p->nx) * ny_local > (1LL << 31) - 4096) { lbm_internal::set_error("lbm_create: partition too large for 32-bit cell indices"); return 1; }
+
+  HIP_TRY(hipSetDevice(device));
+  lbm_ctx* c = new lbm_ctx();
+  c->p = *p;
+  c->free_cells = free_cells;
+  c->free_cells_inv = 1.0f / free_cells;                                    // d2q9-bgk.c:950
+  c->y0 = y0; c->nyl = ny_local; c->device = device; c->flags = flags;
+  c->self_periodic = self_periodic;
+  c->accel_row = accel_row;
+  c->accel_w1 = p->density * p->accel * 0.111111111111111111111111f;        // d2q9-bgk.c:445
+  c->accel_w2 = p->density * p->accel * 0.0277777777777777777777778f;       // d2q9-bgk.c:446
+  c->ncells = static_cast<size_t>(p->nx) * ny_local;
+  c->ps = plane_stride_floats(c->ncells);
+  c->grid_floats = 9 * c->ps + 128;
+  // non-temporal output stores once the two grids no longer fit the 256 MiB Infinity Cache
+  const size_t state_bytes = 2 * 9 * c->ncells * sizeof(float);
+  c->nt_stores = state_bytes > (192u << 20);
+  if (flags & LBM_FLAG_NT_STORES) c->nt_stores = true;
+  if (flags & LBM_FLAG_NO_NT_STORES) c->nt_stores = false;
+
+  auto fail = [&](void) { lbm_destroy(c); return 1; };
+#define HIP_TRY_C(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      lbm_internal::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return fail();                                                                         \
+    }                                                                                        \
+  } while (0)
+
+  HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int g = 0; g < 2; ++g) {
+    HIP_TRY_C(hipMalloc(&c->grid_alloc[g], sizeof(float) * c->grid_floats));
+    HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
+    c->grid[g] = c->grid_alloc[g] + 64;
+  }
+  // obstacle bitfield
+  const size_t mwords = (c->ncells + 31) / 32 + 4;
+  std::vector<uint32_t> bits(mwords, 0u);
+  for (size_t i = 0; i < c->ncells; ++i)
+    if (obstacles_rows[i]) bits[i >> 5] |= 1u << (i & 31);
+  HIP_TRY_C(hipMalloc(&c->mask, sizeof(uint32_t) * mwords));
+  HIP_TRY_C(hipMemcpy(c->mask, bits.data(), sizeof(uint32_t) * mwords, hipMemcpyHostToDevice));
+  // halo buffers: 2 send + 2 recv, each [3][nxp]
+  c->nxp = p->nx + 2 * kHaloGuard;
+  const size_t hb = static_cast<size_t>(3) * c->nxp;
+  HIP_TRY_C(hipMalloc(&c->halo_alloc, sizeof(float) * hb * 4));
+  HIP_TRY_C(hipMemsetAsync(c->halo_alloc, 0, sizeof(float) * hb * 4, c->stream));
+  c->send[0] = c->halo_alloc; c->send[1] = c->halo_alloc + hb;
+  c->recv[0] = c->halo_alloc + 2 * hb; c->recv[1] = c->halo_alloc + 3 * hb;
+  // launch geometry + partial buffers
+  const long long qrow = p->nx / kCellsPerLane;
+  const long long qfull = qrow * ny_local;
+  c->iters_full = pick_iters(qfull);
+  c->n_part_full = blocks_for(qfull, c->iters_full);
+  const long long qint = ny_local > 2 ? qrow * (ny_local - 2) : 0;
+  c->iters_interior = pick_iters(qint > 0 ? qint : 1);
+  c->n_part_interior = qint > 0 ? blocks_for(qint, c->iters_interior) : 0;
+  c->n_part_boundary = blocks_for(ny_local > 1 ? 2 * qrow : qrow, 1);
+  c->partials_cap = std::max(c->n_part_full, c->n_part_interior + c->n_part_boundary) + 1;
+  for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->partials[i], sizeof(double) * c->partials_cap));
+  HIP_TRY_C(hipMalloc(&c->counter, sizeof(int)));
+  HIP_TRY_C(hipMemsetAsync(c->counter, 0, sizeof(int), c->stream));
+  // initial state (d2q9-bgk.c:880-902)
+  {
+    const float w0 = p->density * 4.0f / 9.0f, w1 = p->density / 9.0f, w2 = p->density / 36.0f;
+    const int blocks = static_cast<int>((c->ncells + 255) / 256);
+    hipLaunchKernelGGL(lbm_init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->grid[0], c->ps, c->ncells, w0, w1, w2);
+    HIP_TRY_C(hipGetLastError());
+  }
+  HIP_TRY_C(hipStreamSynchronize(c->stream));
+#undef HIP_TRY_C
+  *out = c;
+  return 0;
+}
+
+int lbm_destroy(lbm_ctx* c)
+{
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int g = 0; g < 2; ++g) if (c->grid_alloc[g]) (void)hipFree(c->grid_alloc[g]);
+  if (c->mask) (void)hipFree(c->mask);
+  if (c->halo_alloc) (void)hipFree(c->halo_alloc);
+  for (int i = 0; i < 2; ++i) if (c->partials[i]) (void)hipFree(c->partials[i]);
+  if (c->sums) (void)hipFree(c->sums);
+  if (c->counter) (void)hipFree(c->counter);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
+{
+  if (!c) { lbm_internal::set_error("lbm_run: null context"); return 1; }
+  if (!c->self_periodic) { lbm_internal::set_error("lbm_run: partition is not a self-contained domain; use the lbm_step_* calls"); return 1; }
+  if (n_steps < 0) { lbm_internal::set_error("lbm_run: negative step count"); return 1; }
+  if (n_steps == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  if (begin_run(c, n_steps, s)) return 1;
+  const long long quads = static_cast<long long>(c->p.nx / kCellsPerLane) * c->nyl;
+  for (int t = 0; t < n_steps; ++t) {
+    StepArgs a = base_args(c, /*accel_next=*/t + 1 < n_steps);
+    a.quad_begin = 0; a.quad_end = static_cast<int>(quads);
+    a.quad_begin2 = a.quad_end2 = 0;
+    a.iters = c->iters_full;
+    a.partials_out = c->partials[c->parity];
+    a.prev_partials = c->partials[c->parity ^ 1];
+    a.n_prev = c->n_prev;
+    launch_step(c, a, c->n_part_full, s);
+    c->n_prev = c->n_part_full;
+    c->parity ^= 1;
+    c->cur ^= 1;
+  }
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->sums, c->counter);
+  HIP_TRY(hipGetLastError());
+  c->n_prev = 0;
+  c->run_done = n_steps;
+  if (av_vels) {
+    std::vector<double> host(static_cast<size_t>(n_steps));
+    HIP_TRY(hipMemcpyAsync(host.data(), c->sums, sizeof(double) * n_steps, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double inv = static_cast<double>(c->free_cells_inv);
+    for (int t = 0; t < n_steps; ++t) av_vels[t] = static_cast<float>(host[t] * inv);   // d2q9-bgk.c:367
+  } else {
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+int lbm_get_cells(lbm_ctx* c, float* cells_aos)
+{
+  if (!c || !cells_aos) { lbm_internal::set_error("lbm_get_cells: null argument"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  float* tmp = nullptr;
+  const size_t n = c->ncells * 9;
+  HIP_TRY(hipMalloc(&tmp, sizeof(float) * n));
+  const int blocks = static_cast<int>((n + 255) / 256);
+  hipLaunchKernelGGL(lbm_soa_to_aos_kernel, dim3(blocks), dim3(256), 0, c->stream, c->grid[c->cur], tmp, c->ps, c->ncells);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(cells_aos, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return 0;
+}
+
+int lbm_set_cells(lbm_ctx* c, const float* cells_aos)
+{
+  if (!c || !cells_aos) { lbm_internal::set_error("lbm_set_cells: null argument"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  float* tmp = nullptr;
+  const size_t n = c->ncells * 9;
+  HIP_TRY(hipMalloc(&tmp, sizeof(float) * n));
+  hipError_t e = hipMemcpyAsync(tmp, cells_aos, sizeof(float) * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    const int blocks = static_cast<int>((n + 255) / 256);
+    hipLaunchKernelGGL(lbm_aos_to_soa_kernel, dim3(blocks), dim3(256), 0, c->stream, tmp, c->grid[c->cur], c->ps, c->ncells);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return 0;
+}
+
+int lbm_av_velocity_sum(lbm_ctx* c, double* tot_u)
+{
+  if (!c || !tot_u) { lbm_internal::set_error("lbm_av_velocity_sum: null argument"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  const int blocks = static_cast<int>(std::min<size_t>((c->ncells + kBlock - 1) / kBlock, 1024));
+  double* part = nullptr;
+  HIP_TRY(hipMalloc(&part, sizeof(double) * blocks));
+  hipLaunchKernelGGL(lbm_av_velocity_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, c->grid[c->cur], c->ps, c->mask, c->ncells, part);
+  std::vector<double> host(blocks);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, sizeof(double) * blocks, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(part);
+  HIP_TRY(e);
+  double s = 0.0;
+  for (double v : host) s += v;
+  *tot_u = s;
+  return 0;
+}
+
+size_t lbm_halo_floats(const lbm_ctx* c) { return c ? static_cast<size_t>(3) * c->nxp : 0; }
+void* lbm_halo_send_ptr(lbm_ctx* c, int dir) { return (c && (dir == 0 || dir == 1)) ? c->send[dir] : nullptr; }
+void* lbm_halo_recv_ptr(lbm_ctx* c, int dir) { return (c && (dir == 0 || dir == 1)) ? c->recv[dir] : nullptr; }
+
+int lbm_bind_halo_buffers(lbm_ctx* c, void* send_south, void* send_north, void* recv_south, void* recv_north)
+{
+  if (!c || !send_south || !send_north || !recv_south || !recv_north) { lbm_internal::set_error("lbm_bind_halo_buffers: null argument"); return 1; }
+  void* ptrs[4] = {send_south, send_north, recv_south, recv_north};
+  for (void* q : ptrs)
+    if (reinterpret_cast<uintptr_t>(q) % 16 != 0) { lbm_internal::set_error("lbm_bind_halo_buffers: buffers must be 16-byte aligned"); return 1; }
+  c->send[0] = static_cast<float*>(send_south); c->send[1] = static_cast<float*>(send_north);
+  c->recv[0] = static_cast<float*>(recv_south); c->recv[1] = static_cast<float*>(recv_north);
+  return 0;
+}
+
+int lbm_step_prepare(lbm_ctx* c, int n_steps, void* stream)
+{
+  if (!c || n_steps < 0) { lbm_internal::set_error("lbm_step_prepare: bad argument"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = pick_stream(c, stream);
+  if (begin_run(c, n_steps, s)) return 1;
+  const int nx = c->p.nx;
+  hipLaunchKernelGGL(lbm_pack_halo_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps, nx, c->nyl, c->nxp,
+                     c->send[0], c->send[1]);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int lbm_step_interior(lbm_ctx* c, void* stream)
+{
+  if (!c) { lbm_internal::set_error("lbm_step_interior: null context"); return 1; }
+  if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_step_interior: no steps left; call lbm_step_prepare"); return 1; }
+  hipStream_t s = pick_stream(c, stream);
+  const int qrow = c->p.nx / kCellsPerLane;
+  StepArgs a = base_args(c, c->run_done + 1 < c->run_steps);
+  a.quad_begin = qrow; a.quad_end = qrow * (c->nyl - 1);
+  a.quad_begin2 = a.quad_end2 = 0;
+  a.iters = c->iters_interior;
+  a.partials_out = c->partials[c->parity];
+  a.prev_partials = c->partials[c->parity ^ 1];
+  a.n_prev = c->n_prev;
+  if (c->n_part_interior > 0) {
+    launch_step(c, a, c->n_part_interior, s);
+    HIP_TRY(hipGetLastError());
+    c->n_prev = 0;   // folded (by block 0 of this launch)
+  }
+  return 0;
+}
+
+int lbm_step_boundary(lbm_ctx* c, void* stream)
+{
+  if (!c) { lbm_internal::set_error("lbm_step_boundary: null context"); return 1; }
+  if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_step_boundary: no steps left; call lbm_step_prepare"); return 1; }
+  hipStream_t s = pick_stream(c, stream);
+  const int qrow = c->p.nx / kCellsPerLane;
+  StepArgs a = base_args(c, c->run_done + 1 < c->run_steps);
+  a.quad_begin = 0; a.quad_end = qrow;
+  if (c->nyl > 1) { a.quad_begin2 = qrow * (c->nyl - 1); a.quad_end2 = qrow * c->nyl; }
+  a.iters = 1;
+  a.south_halo = c->recv[0];
+  a.north_halo = c->recv[1];
+  a.send_south = c->send[0];
+  a.send_north = c->send[1];
+  a.partials_out = c->partials[c->parity] + c->n_part_interior;
+  a.prev_partials = c->partials[c->parity ^ 1];
+  a.n_prev = c->n_prev;   // non-zero only when there was no interior launch to fold it
+  launch_step(c, a, c->n_part_boundary, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int lbm_step_finish(lbm_ctx* c, void* stream)
+{
+  if (!c) { lbm_internal::set_error("lbm_step_finish: null context"); return 1; }
+  hipStream_t s = pick_stream(c, stream);
+  c->n_prev = c->n_part_interior + c->n_part_boundary;
+  c->parity ^= 1;
+  c->cur ^= 1;                                                              // d2q9-bgk.c:376-378
+  c->run_done += 1;
+  if (c->run_done == c->run_steps) {
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->sums, c->counter);
+    HIP_TRY(hipGetLastError());
+    c->n_prev = 0;
+  }
+  return 0;
+}
+
+int lbm_step_collect(lbm_ctx* c, void* stream, double* tot_u_per_step, int n_steps)
+{
+  if (!c || !tot_u_per_step || n_steps > c->run_done) { lbm_internal::set_error("lbm_step_collect: bad argument"); return 1; }
+  hipStream_t s = pick_stream(c, stream);
+  HIP_TRY(hipMemcpyAsync(tot_u_per_step, c->sums, sizeof(double) * n_steps, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+void* lbm_step_sums_device_ptr(lbm_ctx* c) { return c ? c->sums : nullptr; }
+
+int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cells_per_launch, long long* state_bytes)
+{
+  if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
+  if (kernel_name && len) {
+    std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");
+  }
+  if (cells_per_launch) *cells_per_launch = static_cast<long long>(c->ncells);
+  if (state_bytes) *state_bytes = static_cast<long long>(2 * 9 * c->ncells * sizeof(float) + c->ncells / 8);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ — run HERE (the build container), never on the GPU box.
+
+What it does
+  1. builds the checker (`make -C oracle all ref`): the C restatement and, from the sources where
+     they lie under /root/reference, the UNMODIFIED reference binary oracle/_ref/d2q9-bgk_ref;
+  2. copies the reference's DATA files — the four input decks and the shipped golden outputs of
+     its own checker (check/*.dat, gzip'd) — into tests/golden/ (data, not source);
+  3. writes truncated and synthetic decks (inputs only) next to them;
+  4. runs the reference binary and the restatement on every case and REQUIRES byte-identical
+     final_state.dat and av_vels.dat; the common sha256 digests, the Reynolds line and the free-cell
+     count go to digests.json — this is what pins the oracle;
+  5. for the small cases stores the reference binary's parsed outputs in small_cases.npz so GPU
+     tests can compare against reference output values directly.
+
+Reference runs are cached under $FIXTURE_CACHE (default /tmp/lbm_fixture_cache): the full 1024x1024
+deck takes ~5 min per implementation on one core.
+"""
+from __future__ import annotations
+
+import gzip
+import hashlib
+import importlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("REFERENCE_DIR", "/root/reference")
+CACHE = os.environ.get("FIXTURE_CACHE", "/tmp/lbm_fixture_cache")
+DECKS = os.path.join(HERE, "decks")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "d2q9-bgk_ref")
+ORACLE_BIN = os.path.join(ROOT, "oracle", "d2q9_oracle")
+
+sys.path.insert(0, ROOT)
+decks = importlib.import_module("mpilattice-boltzmann_amd.decks")
+Params = decks.Params
+
+SHIPPED = ["128x128", "128x256", "256x256", "1024x1024"]
+
+# name -> (params, obstacle spec).  Obstacle spec: ("file", shipped-deck-name) or
+# ("synthetic", p, seed, walls) or ("custom", callable)
+def _accel_row_blocked(nx, ny):
+    o = np.zeros((ny, nx), np.int32)
+    o[ny - 2, :] = 1          # the accelerated row (d2q9-bgk.c:449) is entirely obstacle
+    o[3, 5:9] = 1
+    return o
+
+
+def _single_column(nx, ny):
+    o = np.zeros((ny, nx), np.int32)
+    o[:, 0] = 1               # wall on x = 0 only: exercises the periodic x wrap against a wall
+    o[ny // 2, nx // 2] = 1
+    return o
+
+
+CASES = {
+    # full shipped decks (BASELINE.json configs 1-3)
+    **{n: (None, ("file", n)) for n in SHIPPED},
+    # shipped decks, truncated so that the CPU suite can run them in seconds
+    "256x256_t1000": (Params(256, 256, 1000, 10, 0.1, 0.005, 1.85), ("file", "256x256")),
+    "1024x1024_t200": (Params(1024, 1024, 200, 10, 0.1, 0.01, 1.85), ("file", "1024x1024")),
+    "128x256_t2000": (Params(128, 256, 2000, 10, 0.1, 0.005, 1.85), ("file", "128x256")),
+    # synthetic decks: edge cases of the path
+    "tiny_8x3": (Params(8, 3, 50, 2, 0.1, 0.005, 1.7), ("synthetic", 0.0, 1, False)),
+    "open_64x48": (Params(64, 48, 300, 8, 0.1, 0.005, 1.85), ("synthetic", 0.0, 1, False)),
+    "rand_64x48": (Params(64, 48, 300, 8, 0.1, 0.005, 1.85), ("synthetic", 0.10, 7, False)),
+    "walls_40x24": (Params(40, 24, 400, 6, 0.2, 0.01, 1.2), ("synthetic", 0.03, 11, True)),
+    "dense_32x32": (Params(32, 32, 200, 4, 0.1, 0.005, 1.0), ("synthetic", 0.5, 3, True)),
+    "strongaccel_32x16": (Params(32, 16, 120, 4, 0.1, 0.9, 1.0), ("synthetic", 0.05, 5, False)),
+    "accelrow_blocked_32x16": (Params(32, 16, 100, 4, 0.1, 0.005, 1.5), ("custom", _accel_row_blocked)),
+    "column_24x20": (Params(24, 20, 250, 4, 0.15, 0.02, 1.9), ("custom", _single_column)),
+    "wide_256x8": (Params(256, 8, 150, 4, 0.1, 0.005, 1.85), ("synthetic", 0.02, 13, False)),
+    "tall_8x256": (Params(8, 256, 150, 4, 0.1, 0.005, 1.85), ("synthetic", 0.02, 17, False)),
+    "synth_512x512_t100": (Params(512, 512, 100, 10, 0.1, 0.005, 1.85), ("synthetic", 0.005, 42, True)),
+}
+SMALL_CELLS = 64 * 48   # cases up to this many cells get their parsed outputs stored
+
+
+def sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def run_cli(binary: str, pfile: str, ofile: str, workdir: str) -> str:
+    os.makedirs(workdir, exist_ok=True)
+    done = os.path.join(workdir, "stdout.txt")
+    if not (os.path.exists(done) and os.path.exists(os.path.join(workdir, "final_state.dat"))):
+        out = subprocess.run([binary, pfile, ofile], cwd=workdir, check=True, capture_output=True, text=True).stdout
+        with open(done, "w") as fh:
+            fh.write(out)
+    return open(done).read()
+
+
+def main() -> None:
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all", "ref"], check=True)
+    assert os.path.exists(REF_BIN), "reference binary was not built (need /root/reference and mpicc)"
+    os.makedirs(DECKS, exist_ok=True)
+    os.makedirs(os.path.join(HERE, "check"), exist_ok=True)
+
+    # 2. the reference's data files
+    for n in SHIPPED:
+        shutil.copyfile(os.path.join(REF, f"input_{n}.params"), os.path.join(DECKS, f"input_{n}.params"))
+        shutil.copyfile(os.path.join(REF, f"obstacles_{n}.dat"), os.path.join(DECKS, f"obstacles_{n}.dat"))
+    for f in sorted(os.listdir(os.path.join(REF, "check"))):
+        if f.endswith(".dat"):
+            with open(os.path.join(REF, "check", f), "rb") as src, \
+                 gzip.GzipFile(os.path.join(HERE, "check", f + ".gz"), "wb", mtime=0) as dst:
+                shutil.copyfileobj(src, dst)
+
+    digests, small = {}, {}
+    for name, (params, ospec) in CASES.items():
+        # 3. inputs
+        if ospec[0] == "file":
+            ofile = os.path.join(DECKS, f"obstacles_{ospec[1]}.dat")
+        else:
+            ofile = os.path.join(DECKS, f"obstacles_{name}.dat")
+            if ospec[0] == "synthetic":
+                obst = decks.synthetic_obstacles(params.nx, params.ny, ospec[1], ospec[2], ospec[3])
+            else:
+                obst = ospec[1](params.nx, params.ny)
+            decks.write_obstacles(ofile, obst)
+        pfile = os.path.join(DECKS, f"input_{name}.params")
+        if params is not None:
+            params.write(pfile)
+
+        # 4. reference vs restatement
+        ref_dir, ora_dir = os.path.join(CACHE, "ref", name), os.path.join(CACHE, "oracle", name)
+        ref_out = run_cli(REF_BIN, pfile, ofile, ref_dir)
+        ora_out = run_cli(ORACLE_BIN, pfile, ofile, ora_dir)
+        entry = {"params": os.path.basename(pfile), "obstacles": os.path.basename(ofile)}
+        for f in ("final_state.dat", "av_vels.dat"):
+            a, b = sha256(os.path.join(ref_dir, f)), sha256(os.path.join(ora_dir, f))
+            if a != b:
+                raise SystemExit(f"{name}: {f} differs between the reference binary and the restatement")
+            entry[f.replace(".dat", "_sha256")] = a
+        ref_re = [l for l in ref_out.splitlines() if l.startswith("Reynolds")][0]
+        ora_re = [l for l in ora_out.splitlines() if l.startswith("Reynolds")][0]
+        if ref_re != ora_re:
+            raise SystemExit(f"{name}: Reynolds line differs: {ref_re!r} vs {ora_re!r}")
+        entry["reynolds_line"] = ref_re
+        entry["ref_elapsed_s"] = float([l for l in ref_out.splitlines() if l.startswith("Elapsed time")][0].split()[2])
+        av = np.loadtxt(os.path.join(ref_dir, "av_vels.dat"), usecols=[1], ndmin=1)
+        entry["av_first"], entry["av_last"], entry["steps"] = float(av[0]), float(av[-1]), int(av.size)
+        digests[name] = entry
+        print(f"{name:28s} identical  {ref_re.split()[-1]}  steps={av.size}", flush=True)
+
+        # 5. parsed reference outputs for the small cases
+        fs = np.loadtxt(os.path.join(ref_dir, "final_state.dat"))
+        if fs.shape[0] <= SMALL_CELLS:
+            small[f"{name}__final_state"] = fs
+            small[f"{name}__av_vels"] = av
+
+    with open(os.path.join(HERE, "digests.json"), "w") as fh:
+        json.dump(digests, fh, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **small)
+    print("wrote digests.json, small_cases.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+"""CPU suite, part 2: the host half of the C ABI (no GPU): exports, parsers with the reference's
+error text, decomposition rule, writers, and that the device path refuses to run without a GPU
+instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol(lbm):
+    header = open(os.path.join(ROOT, "include", "lbm_d2q9.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lbm_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 25
+    nm = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (lbm_[a-z_0-9]+)", nm))
+    assert declared <= exported, declared - exported
+    assert declared == set(lbm.EXPORTS), declared ^ set(lbm.EXPORTS)
+    lib = lbm.load_library()
+    assert lib.lbm_abi_version() == 1
+
+
+def test_cli_binary_links_and_prints_usage(lbm):
+    r = subprocess.run([lbm.CLI_PATH], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr == f"Usage: {lbm.CLI_PATH} <paramfile> <obstaclefile>\n"   # d2q9-bgk.c:1153-1157
+    r = subprocess.run([lbm.CLI_PATH, "/nonexistent.params", "x"], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert re.fullmatch(r"Error at line \d+ of file .*\ncould not open input parameter file: /nonexistent.params\n", r.stderr)
+
+
+FIELDS = ["nx", "ny", "maxIters", "reynolds_dim", "density", "accel", "omega"]
+
+
+@pytest.mark.parametrize("n_ok", range(7))
+def test_read_params_error_names_the_missing_field(lbm, oracle, tmp_path, n_ok):
+    good = ["128", "64", "10", "10", "0.1", "0.005", "1.85"]
+    f = tmp_path / "p.params"
+    f.write_text("\n".join(good[:n_ok] + ["oops"]) + "\n")
+    with pytest.raises(lbm.LbmError, match=f"could not read param file: {FIELDS[n_ok]}$"):
+        lbm.read_params(str(f))
+    with pytest.raises(RuntimeError, match=f"could not read param file: {FIELDS[n_ok]}$"):
+        oracle.read_params(str(f))
+
+
+def test_read_params_values(lbm, tmp_path):
+    f = tmp_path / "p.params"
+    f.write_text("1024 1024\n20000\n10\n0.1\n0.01\n1.85\n")     # any whitespace separates tokens (fscanf)
+    p = lbm.read_params(str(f))
+    assert (p.nx, p.ny, p.max_iters, p.reynolds_dim) == (1024, 1024, 20000, 10)
+    assert np.float32(p.density) == np.float32(0.1) and np.float32(p.omega) == np.float32(1.85)
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("1 1\n", "expected 3 values per line in obstacle file"),
+    ("8 0 1\n", "obstacle x-coord out of range"),
+    ("-1 0 1\n", "obstacle x-coord out of range"),
+    ("0 4 1\n", "obstacle y-coord out of range"),
+    ("0 0 2\n", "obstacle blocked value should be 1"),
+])
+def test_read_obstacles_errors(lbm, oracle, tmp_path, text, msg):
+    f = tmp_path / "o.dat"
+    f.write_text("1 1 1\n" + text)
+    with pytest.raises(lbm.LbmError, match=msg):
+        lbm.read_obstacles(str(f), 8, 4)
+    with pytest.raises(RuntimeError, match=msg):
+        oracle.read_obstacles(str(f), 8, 4)
+    with pytest.raises(lbm.LbmError, match="could not open input obstacles file"):
+        lbm.read_obstacles(str(tmp_path / "missing.dat"), 8, 4)
+
+
+def test_read_obstacles_duplicates_count_once(lbm, oracle, tmp_path):
+    f = tmp_path / "o.dat"
+    f.write_text("1 1 1\n2 3 1\n1 1 1\n7 0 1\n")                # duplicate line, as in the shipped decks
+    obst, free = lbm.read_obstacles(str(f), 8, 4)
+    assert free == 8 * 4 - 3 and obst.sum() == 3 and obst[1, 1] == obst[3, 2] == obst[0, 7] == 1
+    o2, f2 = oracle.read_obstacles(str(f), 8, 4)
+    assert np.array_equal(obst, o2) and free == f2
+    # shipped deck: 512 lines, 508 distinct
+    obst, free = lbm.read_obstacles(os.path.join(GOLDEN, "decks", "obstacles_128x128.dat"), 128, 128)
+    assert obst.sum() == 508 and free == 128 * 128 - 508
+
+
+def test_decompose_follows_the_reference_rule(lbm, oracle):
+    for ny in [3, 8, 64, 127, 128, 129, 130, 191, 256, 1000, 1024, 8192]:
+        for size in [1, 2, 3, 4, 7, 8, 16, 63, 64]:
+            if ny // size < 1:
+                continue
+            a, b = lbm.decompose(ny, size)
+            assert (a, b) == oracle.decompose(ny, size)
+            assert sum(a) == ny and b[0] == 0 and all(b[i + 1] == b[i] + a[i] for i in range(size - 1))
+            if ny // size >= 3 or size == 1 or ny >= 2 * size + 1:
+                assert a[-1] >= 3 or size == 1      # accelerate row never on a sent row (d2q9-bgk.c:848-849)
+    assert lbm.decompose(1024, 8) == ([128] * 8, [128 * i for i in range(8)])
+    assert lbm.decompose(128, 64)[0][-2:] == [1, 3]
+
+
+def test_writers_and_epilogue_match_the_oracle(lbm, oracle, tmp_path):
+    rng = np.random.default_rng(5)
+    p = lbm.Params(16, 6, 3, 7, 0.1, 0.005, 1.3)
+    cells = (rng.random((6, 16, 9), dtype=np.float32) * 0.02 + 0.005).astype(np.float32)
+    obst = (rng.random((6, 16)) < 0.2).astype(np.int32)
+    a, b = str(tmp_path / "a.dat"), str(tmp_path / "b.dat")
+    lbm.write_final_state(a, p, cells, obst)
+    oracle.write_final_state(b, p, cells, obst)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    lbm.write_final_state(a, p, cells[:2], obst[:2], displ=0)
+    lbm.write_final_state(a, p, cells[2:], obst[2:], displ=2, append=True)      # rank-by-rank append (d2q9-bgk.c:1054-1057)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    av = rng.random(5, dtype=np.float32)
+    lbm.write_av_vels(a, av)
+    oracle.write_av_vels(b, av)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(a).readline() == "0:\t%.12E\n" % av[0]
+    assert lbm.av_velocity_host(p, cells, obst) == oracle.av_velocity_sum(p, cells, obst)
+    assert lbm.reynolds(p, 0.0123) == oracle.reynolds(p, 0.0123)
+
+
+def test_device_path_fails_loudly_without_a_gpu(lbm):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = lbm.Params(16, 8, 1, 4, 0.1, 0.005, 1.0)
+    with pytest.raises(lbm.LbmError, match="hip"):
+        lbm.Partition(p, 128, np.zeros((8, 16), np.int32))
+
+
+def test_create_validates_arguments(lbm):
+    lib = lbm.load_library()
+    ctx = C.c_void_p()
+    obst = np.zeros((8, 16), np.int32)
+    for kw, msg in [(dict(nx=18), "multiple of 4"), (dict(ny=2), "ny must be >= 3")]:
+        p = dict(nx=16, ny=8); p.update(kw)
+        cp = lbm._capi.CParams(p["nx"], p["ny"], 1, 4, 0.1, 0.005, 1.0)
+        rc = lib.lbm_create(C.byref(ctx), C.byref(cp), 100, lbm._capi.as_int_ptr(obst), 0, p["ny"], 0, 0)
+        assert rc != 0 and msg in lib.lbm_last_error().decode()
+
+
+def test_synthetic_deck_is_reproducible(lbm, tmp_path):
+    a = lbm.synthetic_obstacles(64, 32, 0.05, 42, True)
+    b = lbm.synthetic_obstacles(64, 32, 0.05, 42, True)
+    assert np.array_equal(a, b) and a[0].all() and a[-1].all() and a[:, 0].all() and a[:, -1].all()
+    assert int(lbm.decks.splitmix64(42, 1)[0]) == 0xBDD732262FEB6E95   # published splitmix64 test vector
+    inner = lbm.synthetic_obstacles(512, 512, 0.005, 42, False)
+    assert 0.003 < inner.mean() < 0.007
+    pp, op = lbm.write_synthetic_deck(str(tmp_path), "t", lbm.Params(64, 32, 5, 4, 0.1, 0.005, 1.85), 0.05, 42)
+    obst, free = lbm.read_obstacles(op, 64, 32)
+    assert np.array_equal(obst, a) and free == 64 * 32 - a.sum()
+    assert lbm.read_params(pp).max_iters == 5
