@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py — MLUPS of the D2Q9-BGK timestep path on MI355X, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 8192x8192]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json config 5, the one the metric's targets are quoted on): the synthetic
+8192x8192 deck of SURVEY.md §8(d) — params 8192, 8192, <steps>, 10, 0.1, 0.005, 1.85; walls on the
+four edges plus interior cells blocked i.i.d. with p = 0.005 from splitmix64(seed 42); initial
+state = the reference's uniform equilibrium.  One "step" = one lattice timestep of the WHOLE grid
+(accelerate_flow + fused propagate/rebound/collision/av_velocity, d2q9-bgk.c:345-367).  With N > 1
+ranks the SAME grid is row-partitioned (d2q9-bgk.c:834-862) over the GPUs — strong scaling — with
+a one-row halo exchange per step over RCCL and one all-reduce of the per-step sums at the end
+(d2q9-bgk.c:396).  The timed region is the reference's (d2q9-bgk.c:278-398): step loop + av_vels
+reduction, inputs resident in HBM, no file I/O.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CELL = 108.0          # 18 reads + 9 writes of fp32 (BASELINE.json north_star)
+PHYS_BYTES_PER_CELL = 72.125         # 9 reads + 9 writes + 1 mask bit actually moved by the pull kernel
+HBM_PEAK_GBS = 8000.0                # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="8192x8192", help="NXxNY of the synthetic deck (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the 1-core baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, obstacles, target_s: float) -> dict:
+    """The oracle (CPU restatement of d2q9-bgk.c's path, digest-pinned to the reference binary) timed
+    on this box's host cores on a bounded sample of the SAME workload: first a few steps on one core
+    (the reference's serial loop), then the row-parallel form on all cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    cells = params.nx * params.ny
+    steps1 = max(2, int(target_s * 85e6 / cells))            # ~85 MLUPS per core expected
+    t = time.perf_counter()
+    oracle_lib.run_fast(params, obstacles, steps1, 1)
+    dt1 = time.perf_counter() - t
+    ncores = len(os.sched_getaffinity(0))
+    stepsn = max(4, int(steps1 * min(ncores, 16) * 0.5))
+    t = time.perf_counter()
+    oracle_lib.run_fast(params, obstacles, stepsn, ncores)
+    dtn = time.perf_counter() - t
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {
+        "value": cells * steps1 / dt1 / 1e6, "unit": "MLUPS", "cores": 1, "kind": "port",
+        "sample": f"{steps1} steps of the same {params.nx}x{params.ny} deck (init + loop, {dt1:.1f} s), gcc -std=c99 -O3",
+        "all_cores": {"value": cells * stepsn / dtn / 1e6, "cores": ncores, "sample": f"{stepsn} steps, {dtn:.1f} s"},
+        "cpu_model": model,
+    }
+
+
+def main() -> None:
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    import mpilattice_boltzmann_amd as lbm
+    if rank == 0:
+        lbm.build()
+    nx, ny = (int(v) for v in args.workload.lower().split("x"))
+    params = lbm.Params(nx, ny, args.steps, 10, 0.1, 0.005, 1.85)
+    obstacles = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    else:
+        torch.cuda.set_device(local_rank)
+    lbm.load_library()
+    sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sim.run(args.warmup)                                  # untimed
+    sync_all()
+    t0 = time.perf_counter()
+    av = sim.run(args.steps)                              # EXACTLY K steps (+ the av_vels reduction, as the reference times it)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert av.shape == (args.steps,) and np.all(np.isfinite(av)) and np.all(av > 0)
+
+    kernel_ms, launches = sim.partition.last_run_kernel_ms()
+    desc = sim.partition.describe()
+    sim.close()
+
+    if rank == 0:
+        cells = nx * ny
+        mlups = cells * args.steps / elapsed / 1e6
+        # dominant kernel: the fused step kernel; average launch duration from HIP events on its stream
+        avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
+        if world == 1:
+            cells_per_launch = desc["cells_per_launch"]
+        else:                                             # interior + boundary launch per step on this rank
+            cells_per_launch = desc["cells_per_launch"] / 2.0
+        achieved = ALGO_BYTES_PER_CELL * cells_per_launch / avg_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("workload") == f"{nx}x{ny}" and world == 1:
+                traffic = t.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "MLUPS", "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
+                                   f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny,
+                       "partitioning": "single GPU" if world == 1 else f"{world} row blocks, 1-row halo exchange (RCCL send/recv), deferred all-reduce"},
+            "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": desc["kernel"],
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "algorithmic_bytes_per_cell": ALGO_BYTES_PER_CELL,
+                         "physical_GBps": PHYS_BYTES_PER_CELL * cells_per_launch / avg_launch_s / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, obstacles, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,12 @@ int    lbm_step_collect(lbm_ctx* ctx, void* stream, double* tot_u_per_step, int 
  * lbm_step_collect or a stream sync following the last lbm_step_finish. */
 void*  lbm_step_sums_device_ptr(lbm_ctx* ctx);
 
+/* Device time of the step kernels of the last completed run (lbm_run, or lbm_step_prepare ..
+ * last lbm_step_finish), from HIP events recorded on the stream the kernels were launched on:
+ * *ms = time from just before the first step kernel to just after the last one, *launches = the
+ * number of step-kernel launches in between.  Valid once that stream has been synchronised. */
+int lbm_last_run_kernel_ms(lbm_ctx* ctx, double* ms, int* launches);
+
 /* Kernel/launch facts for the measurement harness: name of the dominant kernel as rocprofv3
  * prints it, cells per launch, bytes of state in HBM. */
 int lbm_describe(const lbm_ctx* ctx, char* kernel_name, size_t len, long long* cells_per_launch,

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "lbm_step_finish": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_step_collect": (C.c_int, [_ctx, C.c_void_p, _P(C.c_double), C.c_int]),
     "lbm_step_sums_device_ptr": (C.c_void_p, [_ctx]),
+    "lbm_last_run_kernel_ms": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_int)]),
     "lbm_describe": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_longlong), _P(C.c_longlong)]),
     "lbm_av_velocity_host": (C.c_float, [_P(CParams), _P(C.c_float), _P(C.c_int), C.c_int]),
     "lbm_reynolds": (C.c_float, [_P(CParams), C.c_float]),

@@ -419,6 +419,9 @@ struct lbm_ctx {
   int sums_cap = 0;
   int* counter = nullptr;
   hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the step kernels of the last run
+  int ev_launches = 0;
+  bool ev_valid = false;
   // run state (split-phase and lbm_run)
   int run_steps = 0, run_done = 0;
   int parity = 0;            // partials buffer written by the current step
@@ -496,6 +499,9 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
                        c->mask, nx, c->accel_row, c->accel_w1, c->accel_w2);
     HIP_TRY(hipGetLastError());
   }
+  c->ev_valid = false;
+  c->ev_launches = 0;
+  HIP_TRY(hipEventRecord(c->ev_begin, s));
   return 0;
 }
 
@@ -552,6 +558,8 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   } while (0)
 
   HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY_C(hipEventCreate(&c->ev_begin));
+  HIP_TRY_C(hipEventCreate(&c->ev_end));
   for (int g = 0; g < 2; ++g) {
     HIP_TRY_C(hipMalloc(&c->grid_alloc[g], sizeof(float) * c->grid_floats));
     HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
@@ -608,6 +616,8 @@ int lbm_destroy(lbm_ctx* c)
   for (int i = 0; i < 2; ++i) if (c->partials[i]) (void)hipFree(c->partials[i]);
   if (c->sums) (void)hipFree(c->sums);
   if (c->counter) (void)hipFree(c->counter);
+  if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+  if (c->ev_end) (void)hipEventDestroy(c->ev_end);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -637,6 +647,9 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     c->cur ^= 1;
   }
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_end, s));
+  c->ev_launches = n_steps;
+  c->ev_valid = true;
   hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->sums, c->counter);
   HIP_TRY(hipGetLastError());
   c->n_prev = 0;
@@ -789,6 +802,9 @@ int lbm_step_finish(lbm_ctx* c, void* stream)
   c->cur ^= 1;                                                              // d2q9-bgk.c:376-378
   c->run_done += 1;
   if (c->run_done == c->run_steps) {
+    HIP_TRY(hipEventRecord(c->ev_end, s));
+    c->ev_launches = c->run_steps * ((c->n_part_interior > 0 ? 1 : 0) + 1);
+    c->ev_valid = true;
     hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->sums, c->counter);
     HIP_TRY(hipGetLastError());
     c->n_prev = 0;
@@ -806,6 +822,18 @@ int lbm_step_collect(lbm_ctx* c, void* stream, double* tot_u_per_step, int n_ste
 }
 
 void* lbm_step_sums_device_ptr(lbm_ctx* c) { return c ? c->sums : nullptr; }
+
+int lbm_last_run_kernel_ms(lbm_ctx* c, double* ms, int* launches)
+{
+  if (!c || !ms) { lbm_internal::set_error("lbm_last_run_kernel_ms: null argument"); return 1; }
+  if (!c->ev_valid) { lbm_internal::set_error("lbm_last_run_kernel_ms: no completed run"); return 1; }
+  float t = 0.f;
+  HIP_TRY(hipEventSynchronize(c->ev_end));
+  HIP_TRY(hipEventElapsedTime(&t, c->ev_begin, c->ev_end));
+  *ms = t;
+  if (launches) *launches = c->ev_launches;
+  return 0;
+}
 
 int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cells_per_launch, long long* state_bytes)
 {

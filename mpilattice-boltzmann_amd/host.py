@@ -169,6 +169,12 @@ class Partition:
         check(self._lib.lbm_av_velocity_sum(self._ctx, C.byref(tot)))
         return tot.value
 
+    def last_run_kernel_ms(self) -> tuple[float, int]:
+        """(device ms from first to last step kernel of the last run, number of step-kernel launches)."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(self._lib.lbm_last_run_kernel_ms(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def describe(self) -> dict:
         name = C.create_string_buffer(256)
         cells, nbytes = C.c_longlong(0), C.c_longlong(0)

@@ -150,6 +150,9 @@ def main() -> None:
         entry["ref_elapsed_s"] = float([l for l in ref_out.splitlines() if l.startswith("Elapsed time")][0].split()[2])
         av = np.loadtxt(os.path.join(ref_dir, "av_vels.dat"), usecols=[1], ndmin=1)
         entry["av_first"], entry["av_last"], entry["steps"] = float(av[0]), float(av[-1]), int(av.size)
+        # strided sample of the reference binary's av_vels (float serial accumulator): ~64 steps + the last
+        idx = sorted(set(list(range(0, av.size, max(1, av.size // 64))) + [av.size - 1]))
+        entry["av_sample_steps"], entry["av_sample_values"] = idx, [float(av[i]) for i in idx]
         digests[name] = entry
         print(f"{name:28s} identical  {ref_re.split()[-1]}  steps={av.size}", flush=True)
 

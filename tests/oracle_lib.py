@@ -212,3 +212,27 @@ class OraclePartition:
 
     def get_cells(self):
         return self.cells[1:-1].copy()
+
+
+def run_from(p, obstacles: np.ndarray, cells0: np.ndarray, n_steps: int):
+    """d2q9-bgk.c:315-394 for one rank starting from an arbitrary state (small grids: Python loop
+    over steps, C restatement for the rows).  Returns cells, av_exact (float64 per step)."""
+    cp = cparams(p)
+    ny, nx = p.ny, p.nx
+    free = int(obstacles.size - np.count_nonzero(obstacles))
+    inv = np.float32(1.0) / np.float32(free)
+    cells = np.zeros((ny + 2, nx, Q), np.float32)
+    cells[1:-1] = cells0
+    tmp = np.zeros_like(cells)
+    obst = np.zeros((ny + 2, nx), np.int32)
+    obst[1:-1] = obstacles
+    terms = np.zeros((ny + 2, nx), np.float64)
+    out = []
+    for _ in range(n_steps):
+        cells[ny + 1] = cells[1]          # self exchange (:245-247, :295-303)
+        cells[0] = cells[ny]
+        lib().oracle_accelerate_row(C.byref(cp), _f(cells[ny - 1]), _i(obst[ny - 1]))
+        lib().oracle_timestep_rows(C.byref(cp), _f(cells), _f(tmp), _i(obst), 1, ny + 1, _d(terms))
+        out.append(terms[1:-1].sum(axis=1).sum() * np.float64(inv))
+        cells, tmp = tmp, cells
+    return cells[1:-1].copy(), np.asarray(out)

@@ -1,0 +1,232 @@
+"""GPU suite: the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Bar: populations BIT-EXACT (the kernels keep the reference's operation order, unfused, with
+correctly rounded 1/x and sqrt), hence final_state.dat byte-identical to the reference binary's
+(digests.json).  av_vels: the per-cell terms are the reference's, summed as a double tree instead
+of a serial float accumulator, so they are compared (a) with the oracle's double-accumulated
+yardstick at 1e-6 relative and (b) with the reference-order values at the tolerance the float
+accumulator itself allows, and (c) with the shipped goldens under check.py's 1 % rule."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, deck_paths
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["tiny_8x3", "open_64x48", "rand_64x48", "walls_40x24", "dense_32x32", "strongaccel_32x16",
+         "accelrow_blocked_32x16", "column_24x20", "wide_256x8", "tall_8x256", "synth_512x512_t100",
+         "128x256_t2000", "256x256_t1000", "1024x1024_t200"]
+AV_EXACT_RTOL = 1e-6
+
+
+def sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def load_case(lbm, digests, name):
+    ppath, opath = deck_paths(name, digests)
+    p = lbm.read_params(ppath)
+    obst, free = lbm.read_obstacles(opath, p.nx, p.ny)
+    return p, obst, free
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_state_bit_exact_and_files_match_reference_digests(lbm, oracle, digests, tmp_path, name):
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst)
+    av = sim.run()
+    cells = sim.local_cells()
+    re = sim.reynolds(cells)
+    sim.write_values(av, str(tmp_path), cells)
+    sim.close()
+    ref_cells, ref_av, ref_exact = oracle.run(p, obst, p.max_iters, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]     # = the reference binary's file
+    assert "Reynolds number:\t\t%.12E" % re == digests[name]["reynolds_line"]
+    assert av.shape == ref_av.shape
+    assert np.max(np.abs(av.astype(np.float64) - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    assert np.allclose(av, ref_av, rtol=5e-3 if p.nx * p.ny > 100000 else 2e-4)
+
+
+@pytest.mark.parametrize("name", ["128x128", "128x256", "256x256", "1024x1024"])
+def test_cli_on_shipped_decks(lbm, digests, tmp_path, name):
+    """The drop-in CLI on the four shipped decks (BASELINE.json configs): stdout contract, files in
+    cwd, final_state.dat byte-identical to the reference binary's, av_vels inside check.py's 1 %."""
+    ppath, opath = deck_paths(name, digests)
+    r = subprocess.run([lbm.CLI_PATH, ppath, opath], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "==done=="                                                   # d2q9-bgk.c:411-415
+    assert out[1] == digests[name]["reynolds_line"]
+    assert out[2].startswith("Elapsed time:\t\t\t") and out[2].endswith(" (s)")
+    assert out[3].startswith("Elapsed user CPU time:\t\t") and out[4].startswith("Elapsed system CPU time:\t")
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    ck = lbm.checker
+    ref_fs = os.path.join(GOLDEN, "check", f"{name}.final_state.dat.gz")
+    has_fs = os.path.exists(ref_fs)            # 256x256 / 1024x1024 final-state goldens are absent upstream
+    rep = ck.check_files(os.path.join(GOLDEN, "check", f"{name}.av_vels.dat.gz"), ref_fs if has_fs else None,
+                         str(tmp_path / "av_vels.dat"), str(tmp_path / "final_state.dat") if has_fs else None)
+    assert rep.ok, rep.message
+    assert abs(rep.av_vels.max_diff_pcnt) < 0.3
+    # reference-binary av_vels samples (float accumulator) vs ours (double tree)
+    av = ck.load_av_vels(str(tmp_path / "av_vels.dat"))
+    steps = np.asarray(digests[name]["av_sample_steps"])
+    ref = np.asarray(digests[name]["av_sample_values"])
+    assert av.size == digests[name]["steps"]
+    assert np.allclose(av[steps], ref, rtol=4e-3 if name == "1024x1024" else 5e-4)
+
+
+def test_repeated_runs_equal_one_run(lbm, digests):
+    p, obst, _ = load_case(lbm, digests, "rand_64x48")
+    a = lbm.Simulation(p, obst)
+    av_a = a.run(25)
+    b = lbm.Simulation(p, obst)
+    av_b = np.concatenate([b.run(10), b.run(1), b.run(14)])
+    assert np.array_equal(bits(a.local_cells()), bits(b.local_cells()))
+    assert np.array_equal(av_a, av_b)
+    assert b.run(0).size == 0
+    a.close(); b.close()
+
+
+def test_runs_are_deterministic(lbm, digests):
+    p, obst, _ = load_case(lbm, digests, "synth_512x512_t100")
+    res = []
+    for _ in range(2):
+        s = lbm.Simulation(p, obst)
+        res.append((s.run(60), s.local_cells()))
+        s.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(bits(res[0][1]), bits(res[1][1]))
+
+
+@pytest.mark.parametrize("flags", [1, 2])
+def test_store_policy_does_not_change_results(lbm, oracle, digests, flags):
+    p, obst, _ = load_case(lbm, digests, "walls_40x24")
+    s = lbm.Simulation(p, obst, flags=flags)
+    s.run(50)
+    ref_cells, _, _ = oracle.run(p, obst, 50)
+    assert np.array_equal(bits(s.local_cells()), bits(ref_cells))
+    s.close()
+
+
+def test_set_cells_random_state(lbm, oracle):
+    rng = np.random.default_rng(11)
+    p = lbm.Params(48, 20, 8, 4, 0.1, 0.02, 1.6)
+    obst = lbm.synthetic_obstacles(48, 20, 0.08, 9, False)
+    cells0 = (rng.random((20, 48, 9), dtype=np.float32) * 0.02 + 0.004).astype(np.float32)
+    part = lbm.Partition(p, lbm.count_free_cells(obst), obst)
+    part.set_cells(cells0)
+    assert np.array_equal(bits(part.get_cells()), bits(cells0))
+    av = part.run(8)
+    ref_cells, ref_av = oracle.run_from(p, obst, cells0, 8)
+    assert np.array_equal(bits(part.get_cells()), bits(ref_cells))
+    assert np.max(np.abs(av - ref_av) / ref_av) < AV_EXACT_RTOL
+    part.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(4, 3), (8, 3), (4, 64), (2048, 3), (12, 7), (36, 5), (1028, 6)])
+def test_odd_shapes(lbm, oracle, nx, ny):
+    """nx only needs to be a multiple of 4 here (the reference silently needs 8, d2q9-bgk.c:453,520);
+    rows of any count >= 3; tiles that straddle rows."""
+    p = lbm.Params(nx, ny, 30, 4, 0.1, 0.01, 1.4)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.1, nx * 31 + ny, False)
+    if obst.all():
+        obst[0, 0] = 0
+    s = lbm.Simulation(p, obst)
+    av = s.run(30)
+    ref_cells, _, ref_exact = oracle.run(p, obst, 30)
+    assert np.array_equal(bits(s.local_cells()), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL
+    s.close()
+
+
+def test_device_av_velocity_matches_host(lbm, digests):
+    p, obst, free = load_case(lbm, digests, "rand_64x48")
+    s = lbm.Simulation(p, obst)
+    s.run(200)
+    cells = s.local_cells()
+    host = lbm.av_velocity_host(p, cells, obst)
+    dev = s.partition.av_velocity_sum()
+    assert abs(dev - host) / host < 1e-5
+    s.close()
+
+
+def _ring_exchange(parts):
+    """The halo exchange of d2q9-bgk.c:295-313 between partitions that live in one process:
+    southward messages land in the southern neighbour's north halo and vice versa."""
+    n = len(parts)
+    for r, part in enumerate(parts):
+        parts[(r - 1) % n].halo_recv(lbm_NORTH).copy_(part.halo_send(lbm_SOUTH))
+        parts[(r + 1) % n].halo_recv(lbm_SOUTH).copy_(part.halo_send(lbm_NORTH))
+
+
+lbm_SOUTH, lbm_NORTH = 0, 1
+
+
+@pytest.mark.parametrize("case,size", [("rand_64x48", 2), ("rand_64x48", 3), ("rand_64x48", 5), ("walls_40x24", 8),
+                                       ("tall_8x256", 64), ("wide_256x8", 2), ("synth_512x512_t100", 8)])
+def test_row_partitioned_stepping_equals_single_partition(lbm, oracle, digests, case, size):
+    """Split-phase C ABI (interior / boundary / halo buffers) with `size` partitions of one grid on
+    one GPU, exchanged by device copies: must be bit-identical to the single-partition run, and the
+    summed per-step tot_u must match."""
+    import torch
+    p, obst, free = load_case(lbm, digests, case)
+    steps = min(p.max_iters, 60)
+    ny_local, displs = lbm.decompose(p.ny, size)
+    dev = torch.device("cuda", 0)
+    parts = []
+    for r in range(size):
+        part = lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r])
+        part.bind_halo_tensors(dev)
+        parts.append(part)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for part in parts:
+        part.step_prepare(steps, stream)
+    for _ in range(steps):
+        _ring_exchange(parts)
+        for part in parts:
+            part.step_interior(stream)
+            part.step_boundary(stream)
+            part.step_finish(stream)
+    sums = sum(part.step_collect(steps, stream) for part in parts)
+    cells = np.concatenate([part.get_cells() for part in parts], axis=0)
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    av = sums * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+    for part in parts:
+        part.close()
+
+
+def test_full_size_8192_properties_and_short_parity(lbm, oracle):
+    """BASELINE.json config 5 (synthetic 8192x8192, p=0.005, seed 42, walls).  Size-independent
+    properties: mass is conserved by stream + bounce-back + BGK + accelerate (all exchange mass
+    between populations only), obstacle interiors never change, av_vels is positive and grows
+    from rest; plus a short bit-exact comparison with the (multi-threaded) oracle."""
+    n = 8192
+    p = lbm.Params(n, n, 12, 10, 0.1, 0.005, 1.85)
+    obst = lbm.synthetic_obstacles(n, n, 0.005, 42, True)
+    s = lbm.Simulation(p, obst)
+    av = s.run(12)
+    cells = s.local_cells()
+    s.close()
+    mass = cells.sum(dtype=np.float64)
+    mass0 = np.float64(n) * n * (np.float64(np.float32(0.1) * np.float32(4.0) / np.float32(9.0))
+                                 + 4 * np.float64(np.float32(0.1) / np.float32(9.0))
+                                 + 4 * np.float64(np.float32(0.1) / np.float32(36.0)))
+    assert abs(mass - mass0) / mass0 < 1e-6
+    assert np.all(av > 0) and np.all(np.diff(av) > 0)
+    ref_cells, _, ref_exact = oracle.run(p, obst, 12, nthreads=os.cpu_count() or 8)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
