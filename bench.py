@@ -45,6 +45,28 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    box gives one GPU's share of the host, not all the cores /proc/cpuinfo lists)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:                                               # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+    except Exception:
+        try:                                           # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota is not None:
+        return max(1, min(n, int(quota)))
+    return 16 if n > 64 else n                         # no visible quota on a many-core host: one GPU's share is 16 cores
+
+
 def cpu_baseline(params, obstacles, target_s: float) -> dict:
     """The oracle (CPU restatement of d2q9-bgk.c's path, digest-pinned to the reference binary) timed
     on this box's host cores on a bounded sample of the SAME workload: first a few steps on one core
@@ -56,8 +78,8 @@ def cpu_baseline(params, obstacles, target_s: float) -> dict:
     t = time.perf_counter()
     oracle_lib.run_fast(params, obstacles, steps1, 1)
     dt1 = time.perf_counter() - t
-    ncores = len(os.sched_getaffinity(0))
-    stepsn = max(4, int(steps1 * min(ncores, 16) * 0.5))
+    ncores = host_cores()
+    stepsn = max(4, int(steps1 * ncores * 0.4))
     t = time.perf_counter()
     oracle_lib.run_fast(params, obstacles, stepsn, ncores)
     dtn = time.perf_counter() - t

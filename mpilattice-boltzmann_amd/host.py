@@ -203,7 +203,14 @@ class Partition:
 
     @staticmethod
     def _stream_ptr(stream) -> C.c_void_p:
-        return C.c_void_p(stream if isinstance(stream, int) else 0)
+        """stream: None = the context's own stream; otherwise a hipStream_t handle as an int
+        (e.g. torch.cuda.Stream().cuda_stream).  The HIP null stream (handle 0) cannot be named
+        through the ABI — use an explicit stream when kernels must be ordered with other work."""
+        if stream is None:
+            return C.c_void_p(0)
+        if not isinstance(stream, int) or stream == 0:
+            raise ValueError("stream must be None or a non-null hipStream_t handle (create a torch.cuda.Stream)")
+        return C.c_void_p(stream)
 
     def step_prepare(self, n_steps: int, stream=None) -> None:
         check(self._lib.lbm_step_prepare(self._ctx, n_steps, self._stream_ptr(stream)))
@@ -328,10 +335,16 @@ class Simulation:
         self.y0, self.nyl = y0, nyl
         self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device, flags)
         self._torch_device = None
+        self._stream = None
         if self.size > 1:
             import torch
             self._torch_device = torch.device("cuda", device)
-            self.partition.bind_halo_tensors(self._torch_device)
+            # one explicit stream carries the step kernels; RCCL orders its own stream against it
+            # at batch_isend_irecv() (start) and at wait(), so the exchange overlaps step_interior
+            self._stream = torch.cuda.Stream(self._torch_device)
+            with torch.cuda.stream(self._stream):
+                self.partition.bind_halo_tensors(self._torch_device)
+            self._stream.synchronize()
 
     @classmethod
     def from_files(cls, paramfile: str, obstaclefile: str, **kw) -> "Simulation":
@@ -345,8 +358,11 @@ class Simulation:
         if self.size == 1:
             return self.partition.run(n)
         import torch
-        stream = torch.cuda.current_stream(self._torch_device).cuda_stream
-        return run_partitioned(self.partition, self.exchange, n, self.free_cells_inv, self._torch_device, stream)
+        with torch.cuda.stream(self._stream):
+            av = run_partitioned(self.partition, self.exchange, n, self.free_cells_inv, self._torch_device,
+                                 self._stream.cuda_stream)
+        self._stream.synchronize()
+        return av
 
     def local_cells(self) -> np.ndarray:
         return self.partition.get_cells()

@@ -190,16 +190,20 @@ def test_row_partitioned_stepping_equals_single_partition(lbm, oracle, digests, 
         part = lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r])
         part.bind_halo_tensors(dev)
         parts.append(part)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    for part in parts:
-        part.step_prepare(steps, stream)
-    for _ in range(steps):
-        _ring_exchange(parts)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(dev)         # every kernel and every halo copy on ONE explicit stream
+    stream = tstream.cuda_stream
+    with torch.cuda.stream(tstream):
         for part in parts:
-            part.step_interior(stream)
-            part.step_boundary(stream)
-            part.step_finish(stream)
-    sums = sum(part.step_collect(steps, stream) for part in parts)
+            part.step_prepare(steps, stream)
+        for _ in range(steps):
+            _ring_exchange(parts)
+            for part in parts:
+                part.step_interior(stream)
+                part.step_boundary(stream)
+                part.step_finish(stream)
+        sums = sum(part.step_collect(steps, stream) for part in parts)
+    tstream.synchronize()
     cells = np.concatenate([part.get_cells() for part in parts], axis=0)
     ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
     assert np.array_equal(bits(cells), bits(ref_cells))
