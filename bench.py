@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="8192x8192", help="NXxNY of the synthetic deck (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
+                    help="N>1 halo exchange: native RCCL loop (liblbm_d2q9_rccl.so) or torch.distributed P2P ops")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the 1-core baseline sample")
     return ap.parse_args()
 
@@ -123,7 +125,7 @@ def main() -> None:
     else:
         torch.cuda.set_device(local_rank)
     lbm.load_library()
-    sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1)
+    sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=args.exchange)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -169,7 +171,7 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny,
-                       "partitioning": "single GPU" if world == 1 else f"{world} row blocks, 1-row halo exchange (RCCL send/recv), deferred all-reduce"},
+                       "partitioning": "single GPU" if world == 1 else f"{world} row blocks, 1-row halo exchange (RCCL send/recv, {args.exchange} loop), one all-reduce after the loop"},
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": desc["kernel"],

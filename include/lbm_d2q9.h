@@ -46,6 +46,8 @@ typedef struct lbm_ctx lbm_ctx;     /* opaque: device state of one partition */
 #define LBM_FLAG_NT_STORES     1u   /* force non-temporal stores of the output grid (default: auto by size) */
 #define LBM_FLAG_NO_NT_STORES  2u   /* force plain stores */
 #define LBM_FLAG_KERNEL_LDS    4u   /* use the LDS-staged row kernel instead of the direct-load kernel */
+#define LBM_FLAG_FORCE_HALO    8u   /* treat a whole-grid partition like any other rank: edge rows read the halo
+                                       buffers (a 1-rank run that exchanges with itself, d2q9-bgk.c:245-247) */
 
 int         lbm_abi_version(void);
 const char* lbm_last_error(void);
@@ -129,6 +131,11 @@ void*  lbm_step_sums_device_ptr(lbm_ctx* ctx);
  * *ms = time from just before the first step kernel to just after the last one, *launches = the
  * number of step-kernel launches in between.  Valid once that stream has been synchronised. */
 int lbm_last_run_kernel_ms(lbm_ctx* ctx, double* ms, int* launches);
+
+/* The context's HIP device ordinal and its own stream (a hipStream_t as void*): what NULL means
+ * for the `stream` arguments above. */
+int   lbm_device(const lbm_ctx* ctx);
+void* lbm_stream(lbm_ctx* ctx);
 
 /* Kernel/launch facts for the measurement harness: name of the dominant kernel as rocprofv3
  * prints it, cells per launch, bytes of state in HBM. */

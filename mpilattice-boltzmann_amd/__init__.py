@@ -6,16 +6,16 @@ The directory name contains a hyphen; import it as `mpilattice_boltzmann_amd` (a
 repo root) or via importlib.
 """
 from . import _capi, checker, decks
-from ._capi import EXPORTS, LIB_PATH, LbmError, load_library
+from ._capi import EXPORTS, LIB_PATH, LIB_RCCL_PATH, RCCL_EXPORTS, LbmError, load_library, load_rccl_library
 from .build import CLI as CLI_PATH
 from .build import build
 from .decks import Params, synthetic_obstacles, write_obstacles, write_synthetic_deck
-from .host import (NORTH, SOUTH, HaloExchange, Partition, Simulation, av_velocity_host, count_free_cells, decompose,
+from .host import (NORTH, SOUTH, HaloExchange, Partition, RcclRing, Simulation, av_velocity_host, count_free_cells, decompose,
                    read_obstacles, read_params, reynolds, run_partitioned, write_av_vels, write_final_state)
 
 __all__ = [
-    "EXPORTS", "LIB_PATH", "CLI_PATH", "LbmError", "load_library", "build", "Params", "synthetic_obstacles",
-    "write_obstacles", "write_synthetic_deck", "NORTH", "SOUTH", "HaloExchange", "Partition", "Simulation",
+    "EXPORTS", "RCCL_EXPORTS", "LIB_PATH", "LIB_RCCL_PATH", "load_rccl_library", "CLI_PATH", "LbmError", "load_library", "build", "Params", "synthetic_obstacles",
+    "write_obstacles", "write_synthetic_deck", "NORTH", "SOUTH", "HaloExchange", "Partition", "RcclRing", "Simulation",
     "av_velocity_host", "count_free_cells", "decompose", "read_obstacles", "read_params", "reynolds",
     "run_partitioned", "write_av_vels", "write_final_state", "checker", "decks",
 ]

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 ABI_VERSION = 1
 NSPEEDS = 9
 
-FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS = 0, 1, 2, 4
+FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO = 0, 1, 2, 4, 8
 
 
 class LbmError(RuntimeError):
@@ -55,6 +55,8 @@ _SIGNATURES = {
     "lbm_step_collect": (C.c_int, [_ctx, C.c_void_p, _P(C.c_double), C.c_int]),
     "lbm_step_sums_device_ptr": (C.c_void_p, [_ctx]),
     "lbm_last_run_kernel_ms": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_int)]),
+    "lbm_device": (C.c_int, [_ctx]),
+    "lbm_stream": (C.c_void_p, [_ctx]),
     "lbm_describe": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_longlong), _P(C.c_longlong)]),
     "lbm_av_velocity_host": (C.c_float, [_P(CParams), _P(C.c_float), _P(C.c_int), C.c_int]),
     "lbm_reynolds": (C.c_float, [_P(CParams), C.c_float]),
@@ -63,7 +65,34 @@ _SIGNATURES = {
 }
 EXPORTS = tuple(_SIGNATURES)
 
+_RCCL_SIGNATURES = {
+    "lbm_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "lbm_comm_create": (C.c_int, [_P(C.c_void_p), _ctx, C.c_char_p, C.c_int, C.c_int]),
+    "lbm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "lbm_comm_run": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
+}
+RCCL_EXPORTS = tuple(_RCCL_SIGNATURES)
+COMM_ID_BYTES = 128
+LIB_RCCL_PATH = os.path.join(PKG, "lib", "liblbm_d2q9_rccl.so")
+
 _lib = None
+_lib_rccl = None
+
+
+def load_rccl_library() -> C.CDLL:
+    """liblbm_d2q9_rccl.so (include/lbm_d2q9_rccl.h).  torch is imported first so that the process
+    holds ONE RCCL and ONE HIP runtime (torch's bundled ones carry the same SONAMEs)."""
+    global _lib_rccl
+    if _lib_rccl is None:
+        load_library()
+        if not os.path.exists(LIB_RCCL_PATH):
+            raise RuntimeError(f"{LIB_RCCL_PATH} is missing: run build()")
+        lib = C.CDLL(LIB_RCCL_PATH)
+        for name, (res, args) in _RCCL_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib_rccl = lib
+    return _lib_rccl
 
 
 def load_library() -> C.CDLL:
@@ -74,7 +103,11 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP extension is the only implementation of the timestep path)")
-    lib = C.CDLL(LIB_PATH)
+    try:
+        import torch  # noqa: F401  -- first, so its bundled HIP runtime is the only one in the process
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args

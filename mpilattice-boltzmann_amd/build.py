@@ -13,6 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "liblbm_d2q9.so")
+LIB_RCCL = os.path.join(PKG, "lib", "liblbm_d2q9_rccl.so")
 CLI = os.path.join(PKG, "bin", "d2q9-bgk")
 
 # -ffp-contract=off: keep the reference's unfused float arithmetic (bit parity with gcc -std=c99).
@@ -45,13 +46,22 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    rccl_src = [os.path.join(CSRC, "lbm_rccl.cpp")]
+    rccl_hdr = [os.path.join(ROOT, "include", "lbm_d2q9_rccl.h")]
+    if force or _stale(LIB_RCCL, rccl_src + rccl_hdr + headers + [LIB]):
+        # host-only translation unit: the RCCL step loop is a client of the core ABI
+        cmd = [hipcc, *COMMON, "-fPIC", "-shared", *rccl_src, "-L", os.path.dirname(LIB), "-llbm_d2q9", "-lrccl",
+               "-Wl,-rpath,$ORIGIN", "-o", LIB_RCCL]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     cli_src = [os.path.join(CSRC, "d2q9_bgk_main.cpp")]
     if force or _stale(CLI, cli_src + headers + [LIB]):
         cmd = [hipcc, *COMMON, *cli_src, "-L", os.path.dirname(LIB), "-llbm_d2q9", "-Wl,-rpath,$ORIGIN/../lib", "-o", CLI]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return {"lib": LIB, "cli": CLI}
+    return {"lib": LIB, "lib_rccl": LIB_RCCL, "cli": CLI}
 
 
 if __name__ == "__main__":

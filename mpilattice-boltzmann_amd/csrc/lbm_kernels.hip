@@ -518,7 +518,7 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   if (p->ny < 3) { lbm_internal::set_error("lbm_create: ny must be >= 3 (accelerate_flow works on row ny-2, d2q9-bgk.c:449)"); return 1; }
   if (ny_local < 1 || y0 < 0 || y0 + ny_local > p->ny) { lbm_internal::set_error("lbm_create: partition rows out of range"); return 1; }
   if (free_cells <= 0) { lbm_internal::set_error("lbm_create: free_cells must be positive"); return 1; }
-  const bool self_periodic = (ny_local == p->ny);
+  const bool self_periodic = (ny_local == p->ny) && !(flags & LBM_FLAG_FORCE_HALO);
   const int accel_global = p->ny - 2;
   int accel_row = -1;
   if (accel_global >= y0 && accel_global < y0 + ny_local) accel_row = accel_global - y0;
@@ -834,6 +834,9 @@ int lbm_last_run_kernel_ms(lbm_ctx* c, double* ms, int* launches)
   if (launches) *launches = c->ev_launches;
   return 0;
 }
+
+int lbm_device(const lbm_ctx* c) { return c ? c->device : -1; }
+void* lbm_stream(lbm_ctx* c) { return c ? c->stream : nullptr; }
 
 int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cells_per_launch, long long* state_bytes)
 {

@@ -1,0 +1,188 @@
+// lbm_rccl.cpp — row-partitioned step loop with RCCL halo exchange (include/lbm_d2q9_rccl.h).
+//
+// A pure client of the core C ABI (lbm_step_* + halo buffer accessors): this file adds the
+// communicator, two side streams and a few events.  Three queues per rank (reference lines d2q9-bgk.c):
+//
+//   compute stream                 comm stream (high priority)        edge stream (high priority)
+//   ──────────────                 ───────────────────────────        ───────────────────────────
+//   wait(edge_done[t-1])           wait(edge_done[t-1])               wait(halo[t]), wait(interior_done[t-1])
+//   interior kernel t (:350)       group{send S, send N,              boundary kernel t (:365-366): reads the
+//   record(interior_done[t])             recv N, recv S} (:327)        received rows, writes rows 0 / n-1 and the
+//                                  record(halo[t])        (:364)       NEXT step's outgoing messages
+//                                                                     record(edge_done[t])
+//
+// The exchange (2 x 96 KiB at nx = 8192: latency-bound, ~10-15 us) and the two edge rows (~6 us) form
+// a short chain that runs beside the interior kernel (~110 us for 1024 rows of 8192), so a step
+// costs the interior kernel plus one kernel boundary.  Dependencies are exactly the data ones:
+// edge rows of step t need the interior of step t-1 (rows 1 and n-2 as pull sources, and their
+// destination rows are that step's sources); the interior of step t+1 needs the edge rows of step t.
+// xGMI is point-to-point: each of the two messages uses the direct link to its neighbour.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "lbm_d2q9_rccl.h"
+#include "lbm_internal.h"
+
+struct lbm_comm {
+  lbm_ctx* ctx = nullptr;
+  ncclComm_t nccl = nullptr;
+  int nranks = 1, rank = 0, south = 0, north = 0, device = 0;
+  hipStream_t compute = nullptr;   // the context's own stream: interior kernels, folds, final collect
+  hipStream_t side = nullptr;      // exchange stream
+  hipStream_t edge = nullptr;      // boundary-row kernels
+  hipEvent_t halo = nullptr, edge_done = nullptr, interior_done = nullptr;
+  bool three_queues = true;        // edge rows on their own stream beside the interior kernel; LBM_RCCL_SCHEDULE=serial
+                                   // puts them on the compute stream after the interior kernel instead
+};
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      lbm_internal::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+      return 1;                                                                          \
+    }                                                                                    \
+  } while (0)
+
+#define NCCL_TRY(expr)                                                                   \
+  do {                                                                                   \
+    ncclResult_t r_ = (expr);                                                            \
+    if (r_ != ncclSuccess) {                                                             \
+      lbm_internal::set_error(std::string(#expr) + ": " + ncclGetErrorString(r_));       \
+      return 1;                                                                          \
+    }                                                                                    \
+  } while (0)
+
+#define LBM_TRY(expr)                                                                    \
+  do {                                                                                   \
+    if ((expr) != 0) return 1; /* message already set by the core library */             \
+  } while (0)
+
+extern "C" {
+
+int lbm_comm_unique_id(char id[LBM_COMM_ID_BYTES])
+{
+  static_assert(sizeof(ncclUniqueId) == LBM_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  NCCL_TRY(ncclGetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+int lbm_comm_create(lbm_comm** out, lbm_ctx* ctx, const char id[LBM_COMM_ID_BYTES], int nranks, int rank)
+{
+  if (!out || !ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) { lbm_internal::set_error("lbm_comm_create: bad argument"); return 1; }
+  *out = nullptr;
+  lbm_comm* c = new lbm_comm();
+  c->ctx = ctx;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->south = (rank + nranks - 1) % nranks;   // `top`    d2q9-bgk.c:245-246
+  c->north = (rank + 1) % nranks;            // `bottom` d2q9-bgk.c:247
+  c->device = lbm_device(ctx);
+  c->compute = static_cast<hipStream_t>(lbm_stream(ctx));
+  auto fail = [&]() { lbm_comm_destroy(c); return 1; };
+  if (hipSetDevice(c->device) != hipSuccess) { lbm_internal::set_error("lbm_comm_create: hipSetDevice failed"); return fail(); }
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, u, rank);
+  if (r != ncclSuccess) { lbm_internal::set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); c->nccl = nullptr; return fail(); }
+  const char* sched = std::getenv("LBM_RCCL_SCHEDULE");
+  // default by size: three queues pay once the interior kernel is long enough to cover two extra
+  // cross-queue waits (measured on MI355X: 8192x1024 rows 120 vs 133 us/step; 1024x128 rows 55 vs 34)
+  long long cells = 0;
+  (void)lbm_describe(ctx, nullptr, 0, &cells, nullptr);
+  c->three_queues = cells >= (1LL << 21);
+  if (sched && std::string(sched) == "serial") c->three_queues = false;
+  if (sched && std::string(sched) == "edge") c->three_queues = true;
+  // LBM_RCCL_PRIORITY=1: side/edge streams at the highest stream priority (measured: slower)
+  const char* prio = std::getenv("LBM_RCCL_PRIORITY");
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);   // numerically lower = higher priority
+  const int use_prio = (prio && prio[0] == '1') ? prio_high : 0;   // 0 = the normal priority of hipStreamCreate
+  if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, use_prio) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->edge, hipStreamNonBlocking, use_prio) != hipSuccess ||
+      hipEventCreateWithFlags(&c->halo, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->edge_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->interior_done, hipEventDisableTiming) != hipSuccess) {
+    lbm_internal::set_error("lbm_comm_create: stream/event creation failed");
+    return fail();
+  }
+  *out = c;
+  return 0;
+}
+
+int lbm_comm_destroy(lbm_comm* c)
+{
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->edge) (void)hipStreamSynchronize(c->edge);
+  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  if (c->halo) (void)hipEventDestroy(c->halo);
+  if (c->edge_done) (void)hipEventDestroy(c->edge_done);
+  if (c->interior_done) (void)hipEventDestroy(c->interior_done);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->edge) (void)hipStreamDestroy(c->edge);
+  delete c;
+  return 0;
+}
+
+int lbm_comm_run(lbm_comm* c, int n_steps, double* tot_u_per_step)
+{
+  if (!c || n_steps < 0 || (n_steps > 0 && !tot_u_per_step)) { lbm_internal::set_error("lbm_comm_run: bad argument"); return 1; }
+  if (n_steps == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  lbm_ctx* ctx = c->ctx;
+  const size_t n = lbm_halo_floats(ctx);
+  float* send_s = static_cast<float*>(lbm_halo_send_ptr(ctx, 0));
+  float* send_n = static_cast<float*>(lbm_halo_send_ptr(ctx, 1));
+  float* recv_s = static_cast<float*>(lbm_halo_recv_ptr(ctx, 0));
+  float* recv_n = static_cast<float*>(lbm_halo_recv_ptr(ctx, 1));
+
+  LBM_TRY(lbm_step_prepare(ctx, n_steps, nullptr));       // step-0 accelerate_flow + first outgoing rows (compute stream)
+  HIP_TRY(hipEventRecord(c->edge_done, c->compute));      // "edge rows of step -1" = the prepared state
+  HIP_TRY(hipEventRecord(c->interior_done, c->compute));
+  const bool three_queues = c->three_queues;
+  hipStream_t edge_stream = three_queues ? c->edge : c->compute;
+  for (int t = 0; t < n_steps; ++t) {
+    // exchange t: needs the outgoing rows written by the edge kernel of step t-1
+    HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));
+    // sends [south, north] pair with receives [north, south]: the reference's request order
+    // (d2q9-bgk.c:295-303), which also keeps the two messages apart when both neighbours are one rank
+    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(ncclSend(send_s, n, ncclFloat, c->south, c->nccl, c->side));
+    NCCL_TRY(ncclSend(send_n, n, ncclFloat, c->north, c->nccl, c->side));
+    NCCL_TRY(ncclRecv(recv_n, n, ncclFloat, c->north, c->nccl, c->side));
+    NCCL_TRY(ncclRecv(recv_s, n, ncclFloat, c->south, c->nccl, c->side));
+    NCCL_TRY(ncclGroupEnd());                              // MPI_Startall (:327)
+    HIP_TRY(hipEventRecord(c->halo, c->side));
+    // interior t: needs the edge rows of step t-1 (and, by stream order, the interior of step t-1)
+    if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+    LBM_TRY(lbm_step_interior(ctx, c->compute));           // :350, overlaps the exchange
+    // edge rows t: need the halos of step t and the interior of step t-1
+    HIP_TRY(hipStreamWaitEvent(edge_stream, c->halo, 0));  // MPI_Waitall (:364), on the device
+    if (three_queues) HIP_TRY(hipStreamWaitEvent(c->edge, c->interior_done, 0));
+    LBM_TRY(lbm_step_boundary(ctx, edge_stream));          // :365-366
+    HIP_TRY(hipEventRecord(c->edge_done, edge_stream));
+    if (three_queues) {
+      HIP_TRY(hipEventRecord(c->interior_done, c->compute));
+      if (t + 1 == n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));   // the final fold reads both
+    }
+    LBM_TRY(lbm_step_finish(ctx, c->compute));             // :376-378
+  }
+  // MPI_Reduce of the per-step vector (:396), as an in-place all-reduce on the compute stream
+  double* sums = static_cast<double*>(lbm_step_sums_device_ptr(ctx));
+  if (c->nranks > 1) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));
+  LBM_TRY(lbm_step_collect(ctx, nullptr, tot_u_per_step, n_steps));
+  HIP_TRY(hipStreamSynchronize(c->side));
+  HIP_TRY(hipStreamSynchronize(c->edge));
+  return 0;
+}
+
+}  // extern "C"

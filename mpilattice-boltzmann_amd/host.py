@@ -290,6 +290,49 @@ class HaloExchange:
         return t.cpu().numpy()
 
 
+class RcclRing:
+    """The native step loop of liblbm_d2q9_rccl.so for one rank: RCCL send/recv on a side HIP stream
+    overlapped with the interior kernel, one all-reduce at the end (`d2q9-bgk.c:295-313,326-327,364,396`).
+    torch.distributed is used once, to hand rank 0's 128-byte RCCL id to every rank."""
+
+    def __init__(self, partition: "Partition", group=None, *, rank: Optional[int] = None, size: Optional[int] = None):
+        self._lib = _capi.load_rccl_library()
+        self.partition = partition
+        ident = C.create_string_buffer(_capi.COMM_ID_BYTES)
+        if size is None:
+            import torch.distributed as dist
+            rank, size = dist.get_rank(group), dist.get_world_size(group)
+            box = [None]
+            if rank == 0:
+                check(self._lib.lbm_comm_unique_id(ident))
+                box[0] = ident.raw
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            ident = C.create_string_buffer(box[0], _capi.COMM_ID_BYTES)
+        else:                                   # single process (size must be 1): exchange with itself
+            check(self._lib.lbm_comm_unique_id(ident))
+        self.rank, self.size = rank, size
+        self._comm = C.c_void_p()
+        check(self._lib.lbm_comm_create(C.byref(self._comm), partition._ctx, ident, size, rank))
+
+    def run(self, n_steps: int) -> np.ndarray:
+        """Global per-step tot_u (float64, n_steps), identical on every rank."""
+        out = np.zeros(max(n_steps, 1), dtype=np.float64)
+        check(self._lib.lbm_comm_run(self._comm, n_steps, _capi.as_double_ptr(out)))
+        return out[:n_steps]
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None) is not None and self._comm:
+            self._lib.lbm_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_partitioned(part: PartitionBackend, exchange: HaloExchange, n_steps: int, free_cells_inv: np.float32,
                     torch_device="cpu", stream=None) -> np.ndarray:
     """One rank's share of `d2q9-bgk.c:315-396`.  Returns the global av_vels (float32, n_steps)."""
@@ -317,7 +360,9 @@ class Simulation:
     whole grid lives on one GPU and `run()` is a single `lbm_run`."""
 
     def __init__(self, params: Params, obstacles: np.ndarray, *, device: int = 0, flags: int = 0,
-                 distributed: bool = False, group=None):
+                 distributed: bool = False, group=None, exchange: str = "rccl"):
+        """exchange: how a distributed run moves its halos — "rccl" = the native loop of
+        liblbm_d2q9_rccl.so (default), "torch" = torch.distributed P2P ops from Python."""
         obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
         if obstacles.shape != (params.ny, params.nx):
             raise ValueError("obstacles must be (ny, nx)")
@@ -336,7 +381,18 @@ class Simulation:
         self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device, flags)
         self._torch_device = None
         self._stream = None
-        if self.size > 1:
+        self._ring: Optional[RcclRing] = None
+        if exchange not in ("rccl", "torch"):
+            raise ValueError("exchange must be 'rccl' or 'torch'")
+        # a forced-halo whole-grid partition is a 1-rank ring that exchanges with itself (:245-247)
+        self._partitioned = self.size > 1 or bool(flags & _capi.FLAG_FORCE_HALO)
+        if self._partitioned and not distributed:
+            if exchange != "rccl":
+                raise ValueError("a forced-halo run outside torch.distributed needs exchange='rccl'")
+            self._ring = RcclRing(self.partition, rank=0, size=1)
+        elif self._partitioned and exchange == "rccl":
+            self._ring = RcclRing(self.partition, group)
+        elif self._partitioned:
             import torch
             self._torch_device = torch.device("cuda", device)
             # one explicit stream carries the step kernels; RCCL orders its own stream against it
@@ -355,8 +411,11 @@ class Simulation:
     def run(self, n_steps: Optional[int] = None) -> np.ndarray:
         """The timed region of the reference (`d2q9-bgk.c:278-398`): step loop + av_vels reduction."""
         n = self.params.max_iters if n_steps is None else n_steps
-        if self.size == 1:
+        if not self._partitioned:
             return self.partition.run(n)
+        if self._ring is not None:
+            tot = self._ring.run(n)
+            return (tot * np.float64(self.free_cells_inv)).astype(np.float32)          # :367
         import torch
         with torch.cuda.stream(self._stream):
             av = run_partitioned(self.partition, self.exchange, n, self.free_cells_inv, self._torch_device,
@@ -374,6 +433,8 @@ class Simulation:
             return local
         import torch
         import torch.distributed as dist
+        if self._torch_device is None:
+            self._torch_device = torch.device("cuda", self.device)
         mine = torch.from_numpy(local).to(self._torch_device)
         if self.rank == 0:
             parts = [torch.empty((n, self.params.nx, _capi.NSPEEDS), dtype=torch.float32, device=self._torch_device)
@@ -398,4 +459,6 @@ class Simulation:
             write_av_vels(os.path.join(directory, "av_vels.dat"), av_vels)
 
     def close(self) -> None:
+        if self._ring is not None:
+            self._ring.close()
         self.partition.close()

@@ -234,3 +234,42 @@ def test_full_size_8192_properties_and_short_parity(lbm, oracle):
     ref_cells, _, ref_exact = oracle.run(p, obst, 12, nthreads=os.cpu_count() or 8)
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("case", ["rand_64x48", "walls_40x24", "synth_512x512_t100"])
+def test_rccl_ring_of_one_rank(lbm, oracle, digests, case):
+    """The native RCCL step loop (liblbm_d2q9_rccl.so) on a 1-rank ring: the rank sends its edge rows
+    to itself through RCCL on the side stream, exactly the reference's 1-rank behaviour
+    (d2q9-bgk.c:245-247).  Exercises communicator set-up, the event ordering between the exchange
+    and the interior / boundary kernels, and the end-of-run collect."""
+    p, obst, free = load_case(lbm, digests, case)
+    steps = min(p.max_iters, 80)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    av = np.concatenate([sim.run(steps // 2), sim.run(steps - steps // 2)])
+    cells = sim.local_cells()
+    sim.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "torch"])
+def test_distributed_world_of_one_over_nccl(lbm, oracle, digests, tmp_path, exchange):
+    """torch.distributed with the nccl (= RCCL) backend, world size 1: both exchange back ends run
+    their real code path (unique-id broadcast / batch_isend_irecv to self, stream ordering)."""
+    import torch
+    import torch.distributed as dist
+    p, obst, free = load_case(lbm, digests, "rand_64x48")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, distributed=True, exchange=exchange)
+        av = sim.run(60)
+        cells = sim.gather_cells()
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 60)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL

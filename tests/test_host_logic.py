@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol(lbm):
     assert lib.lbm_abi_version() == 1
 
 
+def test_rccl_library_exports_every_declared_symbol(lbm):
+    header = open(os.path.join(ROOT, "include", "lbm_d2q9_rccl.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lbm_comm_[a-z_0-9]+)\s*\(", header))
+    assert declared == {"lbm_comm_unique_id", "lbm_comm_create", "lbm_comm_destroy", "lbm_comm_run"}
+    nm = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_RCCL_PATH], capture_output=True, text=True, check=True).stdout
+    assert declared <= set(re.findall(r" T (lbm_[a-z_0-9]+)", nm))
+    assert declared == set(lbm.RCCL_EXPORTS)
+    lbm.load_rccl_library()
+
+
 def test_cli_binary_links_and_prints_usage(lbm):
     r = subprocess.run([lbm.CLI_PATH], capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr == f"Usage: {lbm.CLI_PATH} <paramfile> <obstaclefile>\n"   # d2q9-bgk.c:1153-1157
