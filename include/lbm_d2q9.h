@@ -46,6 +46,8 @@ typedef struct lbm_ctx lbm_ctx;     /* opaque: device state of one partition */
 #define LBM_FLAG_NT_STORES     1u   /* force non-temporal stores of the output grid (default: auto by size) */
 #define LBM_FLAG_NO_NT_STORES  2u   /* force plain stores */
 #define LBM_FLAG_KERNEL_LDS    4u   /* use the LDS-staged row kernel instead of the direct-load kernel */
+#define LBM_FLAG_GRAPH        16u   /* lbm_run: replay 64-step hipGraphs instead of launching every step (measured: no
+                                       gain on MI355X, the small grids are bound by device-side launch latency) */
 #define LBM_FLAG_FORCE_HALO    8u   /* treat a whole-grid partition like any other rank: edge rows read the halo
                                        buffers (a 1-rank run that exchanges with itself, d2q9-bgk.c:245-247) */
 

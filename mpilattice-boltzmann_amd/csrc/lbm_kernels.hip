@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,6 +51,7 @@ struct StepArgs {
   const float* src;            // source grid, plane 0 row 0
   float* dst;                  // destination grid
   const uint32_t* mask;        // obstacle bitfield, bit c of the partition-local cell index
+  int mask_words;              // words allocated for it
   size_t ps;                   // plane stride in floats
   int nx, nyl;                 // row length, rows owned by this partition
   int quad_begin, quad_end;    // 4-cell groups [begin,end) of the partition handled by this launch
@@ -71,8 +73,23 @@ struct StepArgs {
   int* counter;                // index of the next entry of sums
 };
 
-__device__ __forceinline__ f4 load4(const float* p) { return *reinterpret_cast<const f4*>(p); }
-__device__ __forceinline__ f4 load4u(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+// Kernel variants (template parameter V, bit set):
+constexpr int kNtStores = 1;   // non-temporal stores of the destination grid
+constexpr int kNtLoads = 2;    // non-temporal loads of the source grid            (tuning experiment)
+constexpr int kXcdRemap = 4;   // blocks of one XCD work on one contiguous eighth   (tuning experiment)
+
+template <int V>
+__device__ __forceinline__ f4 load4(const float* p)
+{
+  if (V & kNtLoads) return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+  return *reinterpret_cast<const f4*>(p);
+}
+template <int V>
+__device__ __forceinline__ f4 load4u(const float* p)
+{
+  if (V & kNtLoads) return __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p));
+  return *reinterpret_cast<const f4u*>(p);
+}
 
 template <bool NT>
 __device__ __forceinline__ void store4(float* p, f4 v)
@@ -134,61 +151,45 @@ __device__ __forceinline__ double relax_cell(const float (&t)[9], float omega, f
   return sqrt(static_cast<double>(msq)) * static_cast<double>(rinv);   // :667
 }
 
-// Processes the 4 cells starting at partition-local cell index c (c % 4 == 0, nx % 4 == 0, so
-// the four share a row).  Returns their sum|u| contribution.
-template <bool NT>
-__device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
+// Row bases of the three source rows of destination row y, per population (d2q9-bgk.c:511-512,
+// 526-538): here -> 0,1,3 (+k*ps); south row -> 2,5,6; north row -> 4,7,8.  Rows outside the
+// partition come from the halo messages (row-partitioned runs) or wrap periodically.
+struct RowPtrs {
+  const float *here, *s2, *s5, *s6, *n4, *n7, *n8;
+};
+
+__device__ __forceinline__ RowPtrs source_rows(const StepArgs& a, int y)
 {
-  const int c = quad * kCellsPerLane;
-  const int y = c / a.nx;
-  const int x0 = c - y * a.nx;
+  RowPtrs r;
   const size_t ps = a.ps;
   const int nx = a.nx;
-
-  // row bases of the three source rows, per population group
-  const float* here = a.src + static_cast<size_t>(y) * nx;            // populations 0,1,3: + k*ps
-  const float *s2, *s5, *s6, *n4, *n7, *n8;
+  r.here = a.src + static_cast<size_t>(y) * nx;
   if (y > 0 || a.south_halo == nullptr) {
     const int ys = (y > 0) ? y - 1 : a.nyl - 1;                        // periodic wrap (:245-247 with one rank)
-    const float* r = a.src + static_cast<size_t>(ys) * nx;
-    s2 = r + 2 * ps; s5 = r + 5 * ps; s6 = r + 6 * ps;
+    const float* q = a.src + static_cast<size_t>(ys) * nx;
+    r.s2 = q + 2 * ps; r.s5 = q + 5 * ps; r.s6 = q + 6 * ps;
   } else {
-    const float* r = a.south_halo + kHaloGuard;
-    s2 = r; s5 = r + a.nxp; s6 = r + 2 * a.nxp;
+    const float* q = a.south_halo + kHaloGuard;
+    r.s2 = q; r.s5 = q + a.nxp; r.s6 = q + 2 * a.nxp;
   }
   if (y < a.nyl - 1 || a.north_halo == nullptr) {
     const int yn = (y < a.nyl - 1) ? y + 1 : 0;
-    const float* r = a.src + static_cast<size_t>(yn) * nx;
-    n4 = r + 4 * ps; n7 = r + 7 * ps; n8 = r + 8 * ps;
+    const float* q = a.src + static_cast<size_t>(yn) * nx;
+    r.n4 = q + 4 * ps; r.n7 = q + 7 * ps; r.n8 = q + 8 * ps;
   } else {
-    const float* r = a.north_halo + kHaloGuard;
-    n4 = r; n7 = r + a.nxp; n8 = r + 2 * a.nxp;
+    const float* q = a.north_halo + kHaloGuard;
+    r.n4 = q; r.n7 = q + a.nxp; r.n8 = q + 2 * a.nxp;
   }
+  return r;
+}
 
-  // pull (d2q9-bgk.c:530-538): aligned for x, dword-shifted for x-1 / x+1
-  f4 p[9];
-  p[0] = load4(here + x0);
-  p[2] = load4(s2 + x0);
-  p[4] = load4(n4 + x0);
-  p[1] = load4u(here + ps + x0 - 1);
-  p[5] = load4u(s5 + x0 - 1);
-  p[8] = load4u(n8 + x0 - 1);
-  p[3] = load4u(here + 3 * ps + x0 + 1);
-  p[6] = load4u(s6 + x0 + 1);
-  p[7] = load4u(n7 + x0 + 1);
-  const uint32_t mword = a.mask[c >> 5];
-  if (x0 == 0) {                       // x_w wraps to nx-1 (:529)
-    p[1].x = here[ps + nx - 1];
-    p[5].x = s5[nx - 1];
-    p[8].x = n8[nx - 1];
-  }
-  if (x0 == nx - kCellsPerLane) {      // x_e wraps to 0 (:527-528)
-    p[3].w = here[3 * ps];
-    p[6].w = s6[0];
-    p[7].w = n7[0];
-  }
-  const uint32_t mbits = (mword >> (c & 31)) & 0xFu;
-
+// Everything after the pull for the 4 cells at (y, x0..x0+3), partition-local cell index c:
+// relaxation / bounce-back select, next step's accelerate_flow on row ny-2, stores, outgoing halo
+// rows.  p[k] = streamed-in population k of the four cells.  Returns their sum|u| contribution.
+template <bool NT>
+__device__ __forceinline__ double finish_quad(const StepArgs& a, int c, int y, int x0, const f4 (&p)[9], uint32_t mbits)
+{
+  const size_t ps = a.ps;
   f4 out[9];
   double acc = 0.0;
 #pragma unroll
@@ -240,12 +241,156 @@ __device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
   return acc;
 }
 
+// Direct-load form: processes the 4 cells starting at partition-local cell index 4*quad
+// (nx % 4 == 0, so the four share a row).
+template <int V>
+__device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
+{
+  const int c = quad * kCellsPerLane;
+  const int y = c / a.nx;
+  const int x0 = c - y * a.nx;
+  const size_t ps = a.ps;
+  const int nx = a.nx;
+  const RowPtrs r = source_rows(a, y);
+
+  // pull (d2q9-bgk.c:530-538): aligned for x, dword-shifted for x-1 / x+1
+  f4 p[9];
+  p[0] = load4<V>(r.here + x0);
+  p[2] = load4<V>(r.s2 + x0);
+  p[4] = load4<V>(r.n4 + x0);
+  p[1] = load4u<V>(r.here + ps + x0 - 1);
+  p[5] = load4u<V>(r.s5 + x0 - 1);
+  p[8] = load4u<V>(r.n8 + x0 - 1);
+  p[3] = load4u<V>(r.here + 3 * ps + x0 + 1);
+  p[6] = load4u<V>(r.s6 + x0 + 1);
+  p[7] = load4u<V>(r.n7 + x0 + 1);
+  const uint32_t mword = a.mask[c >> 5];
+  if (x0 == 0) {                       // x_w wraps to nx-1 (:529)
+    p[1].x = r.here[ps + nx - 1];
+    p[5].x = r.s5[nx - 1];
+    p[8].x = r.n8[nx - 1];
+  }
+  if (x0 == nx - kCellsPerLane) {      // x_e wraps to 0 (:527-528)
+    p[3].w = r.here[3 * ps];
+    p[6].w = r.s6[0];
+    p[7].w = r.n7[0];
+  }
+  const uint32_t mbits = (mword >> (c & 31)) & 0xFu;
+  return finish_quad<(V & kNtStores) != 0>(a, c, y, x0, p, mbits);
+}
+
+// LDS-staged form (LBM_FLAG_KERNEL_LDS), the tiling BASELINE.json's north_star sentence describes:
+// every global load is 16-byte aligned; the x-1 / x+1 values a lane needs from its neighbours'
+// vectors travel through an LDS tile row with one halo column per side (filled from global memory
+// by the first / last lane of the block), and the chunk's 1024 obstacle bits sit in LDS as a
+// bitfield.  Same arithmetic, same results; kept as a measured alternative.
+struct LdsTile {
+  float w[3][kBlock + 2];      // [k][1+lane] = .w of populations 1,5,8 of that lane: the x-1 source of lane+1; [0] = halo
+  float e[3][kBlock + 2];      // [k][1+lane] = .x of populations 3,6,7: the x+1 source of lane-1; [kBlock+1] = halo
+  uint32_t mask[kBlock / 8 + 1];   // the (up to) 33 words holding the chunk's 1024 obstacle bits
+};
+
+template <bool NT>
+__device__ __forceinline__ double step_quad_lds(const StepArgs& a, int quad, bool active, int chunk_first_cell, LdsTile& tile)
+{
+  const int tid = threadIdx.x;
+  const int c = quad * kCellsPerLane;
+  const int y = active ? c / a.nx : 0;
+  const int x0 = c - y * a.nx;
+  const size_t ps = a.ps;
+  const int nx = a.nx;
+  const int word0 = chunk_first_cell >> 5;
+  f4 p[9];
+  float hw[3] = {0.f, 0.f, 0.f}, he[3] = {0.f, 0.f, 0.f};
+  const bool row_start = active && x0 == 0;                       // x_w wraps to nx-1 (:529)
+  const bool row_end = active && x0 == nx - kCellsPerLane;        // x_e wraps to 0   (:527-528)
+  if (tid <= kBlock / 8 && word0 + tid < a.mask_words) tile.mask[tid] = a.mask[word0 + tid];
+  if (active) {
+    const RowPtrs r = source_rows(a, y);
+    p[0] = load4<0>(r.here + x0);
+    p[1] = load4<0>(r.here + ps + x0);
+    p[2] = load4<0>(r.s2 + x0);
+    p[3] = load4<0>(r.here + 3 * ps + x0);
+    p[4] = load4<0>(r.n4 + x0);
+    p[5] = load4<0>(r.s5 + x0);
+    p[6] = load4<0>(r.s6 + x0);
+    p[7] = load4<0>(r.n7 + x0);
+    p[8] = load4<0>(r.n8 + x0);
+    tile.w[0][tid + 1] = p[1].w; tile.w[1][tid + 1] = p[5].w; tile.w[2][tid + 1] = p[8].w;
+    tile.e[0][tid + 1] = p[3].x; tile.e[1][tid + 1] = p[6].x; tile.e[2][tid + 1] = p[7].x;
+    // halo columns of the tile row (only the block's first / last lane have no neighbour lane) and
+    // the periodic wrap for lanes sitting on a row edge inside the block
+    if (tid == 0 || row_start) {
+      const int xw = row_start ? nx - 1 : x0 - 1;
+      hw[0] = r.here[ps + xw]; hw[1] = r.s5[xw]; hw[2] = r.n8[xw];
+      if (tid == 0) { tile.w[0][0] = hw[0]; tile.w[1][0] = hw[1]; tile.w[2][0] = hw[2]; }
+    }
+    if (tid == kBlock - 1 || row_end) {
+      const int xe = row_end ? 0 : x0 + kCellsPerLane;
+      he[0] = r.here[3 * ps + xe]; he[1] = r.s6[xe]; he[2] = r.n7[xe];
+      if (tid == kBlock - 1) { tile.e[0][kBlock + 1] = he[0]; tile.e[1][kBlock + 1] = he[1]; tile.e[2][kBlock + 1] = he[2]; }
+    }
+  }
+  __syncthreads();
+  double acc = 0.0;
+  if (active) {
+    const float w1 = row_start ? hw[0] : tile.w[0][tid], w5 = row_start ? hw[1] : tile.w[1][tid],
+                w8 = row_start ? hw[2] : tile.w[2][tid];
+    const float e3 = row_end ? he[0] : tile.e[0][tid + 2], e6 = row_end ? he[1] : tile.e[1][tid + 2],
+                e7 = row_end ? he[2] : tile.e[2][tid + 2];
+    const f4 c1 = p[1], c5 = p[5], c8 = p[8], c3 = p[3], c6 = p[6], c7 = p[7];
+    p[1] = f4{w1, c1.x, c1.y, c1.z};
+    p[5] = f4{w5, c5.x, c5.y, c5.z};
+    p[8] = f4{w8, c8.x, c8.y, c8.z};
+    p[3] = f4{c3.y, c3.z, c3.w, e3};
+    p[6] = f4{c6.y, c6.z, c6.w, e6};
+    p[7] = f4{c7.y, c7.z, c7.w, e7};
+    const uint32_t mbits = (tile.mask[(c >> 5) - word0] >> (c & 31)) & 0xFu;
+    acc = finish_quad<NT>(a, c, y, x0, p, mbits);
+  }
+  __syncthreads();   // the tile is rewritten by the next chunk
+  return acc;
+}
+
+// Same grid / chunk mapping as lbm_step_kernel, single contiguous quad range only (the two-row
+// boundary launch of a row-partitioned run always uses the direct form).
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) lbm_step_kernel_lds(const StepArgs a)
+{
+  __shared__ double red[kBlock / 64];
+  __shared__ LdsTile tile;
+  if (blockIdx.x == 0 && a.n_prev > 0) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s += a.prev_partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+      const int t = *a.counter;
+      a.sums[t] = s;
+      *a.counter = t + 1;
+    }
+  }
+  double acc = 0.0;
+  const int n1 = a.quad_end - a.quad_begin;
+  for (int i = 0; i < a.iters; ++i) {
+    const int r0 = (blockIdx.x * a.iters + i) * kBlock;      // block-uniform: every lane reaches the barriers
+    if (r0 >= n1) break;
+    const int r = r0 + threadIdx.x;
+    acc += step_quad_lds<NT>(a, a.quad_begin + r, r < n1, (a.quad_begin + r0) * kCellsPerLane, tile);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) a.partials_out[blockIdx.x] = acc;
+}
+
 // The fused streaming-pull step.  Grid: ceil(#quads / (256*iters)) blocks of 256 lanes; block b
 // owns `iters` consecutive 1024-cell chunks.
-template <bool NT>
+template <int V>
 __global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
 {
   __shared__ double red[kBlock / 64];
+  // logical block: with kXcdRemap the blocks that share an XCD (dispatch deals blocks round-robin
+  // over the 8 XCDs: b and b+8 share one) take one contiguous eighth of the grid each
+  const int lblock = (V & kXcdRemap) ? static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
+                                     : static_cast<int>(blockIdx.x);
 
   // block 0: fold the previous step's per-block sums into sums[counter++] (d2q9-bgk.c:367)
   if (blockIdx.x == 0 && a.n_prev > 0) {
@@ -262,13 +407,13 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
   double acc = 0.0;
   const int n1 = a.quad_end - a.quad_begin;
   const int n2 = a.quad_end2 > a.quad_begin2 ? a.quad_end2 - a.quad_begin2 : 0;
-  const int base = blockIdx.x * a.iters * kBlock + threadIdx.x;
+  const int base = lblock * a.iters * kBlock + threadIdx.x;
   for (int i = 0; i < a.iters; ++i) {
     const int r = base + i * kBlock;
-    if (r < n1 + n2) acc += step_quad<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
+    if (r < n1 + n2) acc += step_quad<V>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[blockIdx.x] = acc;
+  if (threadIdx.x == 0) a.partials_out[lblock] = acc;
 }
 
 // Folds the last step's partials after the loop.
@@ -383,11 +528,17 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // Plane stride: rows*nx floats + guard for the dword-shifted loads at both ends, rounded to 256 B,
 // then skewed by an odd number of 256-B units so the 9 planes (and the two grids) do not all start
 // on the same HBM channel when rows*nx is a large power of two.
+int tune_env(const char* name, int dflt)
+{
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
+}
+
 size_t plane_stride_floats(size_t ncells)
 {
   size_t s = round_up(ncells + 64, 64);
   if ((s / 64) % 2 == 0) s += 64;
-  if (ncells >= (1u << 20)) s += 64 * 34;   // ~8.5 KiB skew between planes for large grids
+  if (ncells >= (1u << 20)) s += 64 * static_cast<size_t>(tune_env("LBM_TUNE_SKEW", 34));   // default ~8.5 KiB skew between planes for large grids
   return s;
 }
 
@@ -402,11 +553,14 @@ struct lbm_ctx {
   bool self_periodic = true;
   int accel_row = -1;
   bool nt_stores = false;
+  int tune_variant = 0;      // LBM_TUNE_VARIANT: kNtLoads | kXcdRemap experiments
   size_t ncells = 0, ps = 0, grid_floats = 0;
   float* grid_alloc[2] = {nullptr, nullptr};
   float* grid[2] = {nullptr, nullptr};       // plane 0 row 0 (after the front guard)
   int cur = 0;
   uint32_t* mask = nullptr;
+  int mask_words = 0;
+  bool lds_kernel = false;   // LBM_FLAG_KERNEL_LDS
   int nxp = 0;
   float* halo_alloc = nullptr;
   float* send[2] = {nullptr, nullptr};
@@ -419,6 +573,10 @@ struct lbm_ctx {
   int sums_cap = 0;
   int* counter = nullptr;
   hipStream_t stream = nullptr;
+  // launch-bound grids: kGraphSteps steps captured once into a hipGraph and replayed (one per
+  // starting source grid); see lbm_run
+  bool use_graph = false;
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the step kernels of the last run
   int ev_launches = 0;
   bool ev_valid = false;
@@ -435,8 +593,9 @@ int pick_iters(long long quads)
 {
   // keep the grid at <= ~4096 blocks (16 per CU): fewer, longer blocks and a short partial vector
   long long chunks = (quads + kBlock - 1) / kBlock;
+  const int max_blocks = tune_env("LBM_TUNE_MAXBLOCKS", 16384);   // measured on 8192x8192: 16384 blocks x 4 chunks ~7 % faster than 4096 x 16
   int iters = 1;
-  while (chunks / iters > 4096 && iters < 64) iters *= 2;
+  while (chunks / iters > max_blocks && iters < 1024) iters *= 2;
   return iters;
 }
 
@@ -448,9 +607,18 @@ int blocks_for(long long quads, int iters)
 
 hipStream_t pick_stream(lbm_ctx* c, void* stream) { return stream ? static_cast<hipStream_t>(stream) : c->stream; }
 
+void drop_graphs(lbm_ctx* c)
+{
+  for (hipGraphExec_t& g : c->graph_exec) {
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+}
+
 int ensure_sums(lbm_ctx* c, int n)
 {
   if (n <= c->sums_cap) return 0;
+  drop_graphs(c);   // captured kernel arguments hold the old pointer
   if (c->sums) HIP_TRY(hipFree(c->sums));
   c->sums = nullptr;
   c->sums_cap = 0;
@@ -465,6 +633,7 @@ StepArgs base_args(lbm_ctx* c, bool accel_next)
   a.src = c->grid[c->cur];
   a.dst = c->grid[c->cur ^ 1];
   a.mask = c->mask;
+  a.mask_words = c->mask_words;
   a.ps = c->ps;
   a.nx = c->p.nx;
   a.nyl = c->nyl;
@@ -480,8 +649,23 @@ StepArgs base_args(lbm_ctx* c, bool accel_next)
 
 void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 {
-  if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, a);
-  else hipLaunchKernelGGL(lbm_step_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, a);
+  if (c->lds_kernel && a.quad_begin2 >= a.quad_end2) {
+    if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel_lds<true>, dim3(blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(lbm_step_kernel_lds<false>, dim3(blocks), dim3(kBlock), 0, s, a);
+    return;
+  }
+  int v = (c->nt_stores ? kNtStores : 0) | c->tune_variant;
+  if ((v & kXcdRemap) && (blocks % 8 != 0 || blocks < 64)) v &= ~kXcdRemap;
+  switch (v) {
+    case 0: hipLaunchKernelGGL(lbm_step_kernel<0>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(lbm_step_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(lbm_step_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(lbm_step_kernel<3>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lbm_step_kernel<4>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(lbm_step_kernel<5>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    case 6: hipLaunchKernelGGL(lbm_step_kernel<6>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+    default: hipLaunchKernelGGL(lbm_step_kernel<7>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+  }
 }
 
 int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
@@ -502,6 +686,44 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
   c->ev_valid = false;
   c->ev_launches = 0;
   HIP_TRY(hipEventRecord(c->ev_begin, s));
+  return 0;
+}
+
+constexpr int kGraphSteps = 64;   // even: the source/destination roles and the partial-sum parity return to their start
+
+// One whole-grid step of a self-contained domain: launch + state flip (d2q9-bgk.c:345-378).
+void full_step(lbm_ctx* c, bool accel_next, hipStream_t s)
+{
+  const long long quads = static_cast<long long>(c->p.nx / kCellsPerLane) * c->nyl;
+  StepArgs a = base_args(c, accel_next);
+  a.quad_begin = 0; a.quad_end = static_cast<int>(quads);
+  a.quad_begin2 = a.quad_end2 = 0;
+  a.iters = c->iters_full;
+  a.partials_out = c->partials[c->parity];
+  a.prev_partials = c->partials[c->parity ^ 1];
+  a.n_prev = c->n_prev;
+  launch_step(c, a, c->n_part_full, s);
+  c->n_prev = c->n_part_full;
+  c->parity ^= 1;
+  c->cur ^= 1;
+}
+
+// Captures kGraphSteps mid-run steps (previous partials to fold, accelerate epilogue on) starting
+// from the current source grid.  Every per-step quantity that changes from step to step lives on
+// the device (sums[counter++]), so the same graph replays anywhere inside a run.
+int ensure_graph(lbm_ctx* c, hipStream_t s)
+{
+  if (c->graph_exec[c->cur]) return 0;
+  const int cur = c->cur, parity = c->parity, n_prev = c->n_prev;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < kGraphSteps; ++i) full_step(c, true, s);
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  c->cur = cur; c->parity = parity; c->n_prev = n_prev;   // nothing ran
+  HIP_TRY(e);
+  e = hipGraphInstantiate(&c->graph_exec[cur], graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIP_TRY(e);
   return 0;
 }
 
@@ -546,6 +768,12 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   c->nt_stores = state_bytes > (192u << 20);
   if (flags & LBM_FLAG_NT_STORES) c->nt_stores = true;
   if (flags & LBM_FLAG_NO_NT_STORES) c->nt_stores = false;
+  c->tune_variant = tune_env("LBM_TUNE_VARIANT", 0) & (kNtLoads | kXcdRemap);
+  c->lds_kernel = (flags & LBM_FLAG_KERNEL_LDS) != 0;
+  // hipGraph replay of 64-step blocks is opt-in: measured on MI355X it changes nothing (128x128:
+  // 4.47 vs 4.33 us/step) because even the smallest grids are bound by the device-side kernel
+  // boundary + kernel latency, not by the host's launch rate
+  c->use_graph = self_periodic && (flags & LBM_FLAG_GRAPH);
 
   auto fail = [&](void) { lbm_destroy(c); return 1; };
 #define HIP_TRY_C(expr)                                                                      \
@@ -560,16 +788,26 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY_C(hipEventCreate(&c->ev_begin));
   HIP_TRY_C(hipEventCreate(&c->ev_end));
-  for (int g = 0; g < 2; ++g) {
-    HIP_TRY_C(hipMalloc(&c->grid_alloc[g], sizeof(float) * c->grid_floats));
-    HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
-    c->grid[g] = c->grid_alloc[g] + 64;
+  if (tune_env("LBM_TUNE_ONEALLOC", 0)) {
+    // both grids in one allocation: fixed relative placement (tuning experiment)
+    const size_t gap = 64 * static_cast<size_t>(tune_env("LBM_TUNE_GRIDGAP", 0));
+    HIP_TRY_C(hipMalloc(&c->grid_alloc[0], sizeof(float) * (2 * c->grid_floats + gap)));
+    HIP_TRY_C(hipMemsetAsync(c->grid_alloc[0], 0, sizeof(float) * (2 * c->grid_floats + gap), c->stream));
+    c->grid[0] = c->grid_alloc[0] + 64;
+    c->grid[1] = c->grid_alloc[0] + c->grid_floats + gap + 64;
+  } else {
+    for (int g = 0; g < 2; ++g) {
+      HIP_TRY_C(hipMalloc(&c->grid_alloc[g], sizeof(float) * c->grid_floats));
+      HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
+      c->grid[g] = c->grid_alloc[g] + 64;
+    }
   }
   // obstacle bitfield
   const size_t mwords = (c->ncells + 31) / 32 + 4;
   std::vector<uint32_t> bits(mwords, 0u);
   for (size_t i = 0; i < c->ncells; ++i)
     if (obstacles_rows[i]) bits[i >> 5] |= 1u << (i & 31);
+  c->mask_words = static_cast<int>(mwords);
   HIP_TRY_C(hipMalloc(&c->mask, sizeof(uint32_t) * mwords));
   HIP_TRY_C(hipMemcpy(c->mask, bits.data(), sizeof(uint32_t) * mwords, hipMemcpyHostToDevice));
   // halo buffers: 2 send + 2 recv, each [3][nxp]
@@ -610,6 +848,7 @@ int lbm_destroy(lbm_ctx* c)
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drop_graphs(c);
   for (int g = 0; g < 2; ++g) if (c->grid_alloc[g]) (void)hipFree(c->grid_alloc[g]);
   if (c->mask) (void)hipFree(c->mask);
   if (c->halo_alloc) (void)hipFree(c->halo_alloc);
@@ -632,19 +871,17 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   if (begin_run(c, n_steps, s)) return 1;
-  const long long quads = static_cast<long long>(c->p.nx / kCellsPerLane) * c->nyl;
-  for (int t = 0; t < n_steps; ++t) {
-    StepArgs a = base_args(c, /*accel_next=*/t + 1 < n_steps);
-    a.quad_begin = 0; a.quad_end = static_cast<int>(quads);
-    a.quad_begin2 = a.quad_end2 = 0;
-    a.iters = c->iters_full;
-    a.partials_out = c->partials[c->parity];
-    a.prev_partials = c->partials[c->parity ^ 1];
-    a.n_prev = c->n_prev;
-    launch_step(c, a, c->n_part_full, s);
-    c->n_prev = c->n_part_full;
-    c->parity ^= 1;
-    c->cur ^= 1;
+  for (int t = 0; t < n_steps;) {
+    // launch-bound grids: replay a captured block of kGraphSteps steps while at least one more
+    // step follows it (the last step of a run is launched directly: it must not accelerate)
+    if (c->use_graph && c->n_prev > 0 && n_steps - t > kGraphSteps) {
+      if (ensure_graph(c, s)) return 1;
+      HIP_TRY(hipGraphLaunch(c->graph_exec[c->cur], s));
+      t += kGraphSteps;
+    } else {
+      full_step(c, /*accel_next=*/t + 1 < n_steps, s);
+      t += 1;
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_end, s));
@@ -842,7 +1079,8 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");
+    if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
+    else std::snprintf(kernel_name, len, "lbm_step_kernel<%d>", (c->nt_stores ? kNtStores : 0) | c->tune_variant);
   }
   if (cells_per_launch) *cells_per_launch = static_cast<long long>(c->ncells);
   if (state_bytes) *state_bytes = static_cast<long long>(2 * 9 * c->ncells * sizeof(float) + c->ncells / 8);

@@ -273,3 +273,56 @@ def test_distributed_world_of_one_over_nccl(lbm, oracle, digests, tmp_path, exch
     ref_cells, _, ref_exact = oracle.run(p, obst, 60)
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+def test_graph_replay_equals_direct_launches(lbm, digests):
+    """With LBM_FLAG_GRAPH lbm_run replays 64-step hipGraphs; by default it launches every step.
+    Both must give the same bits, for step counts around the block size and across calls."""
+    p, obst, _ = load_case(lbm, digests, "rand_64x48")
+    for steps in (1, 2, 64, 65, 66, 129, 130, 300):
+        a = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_GRAPH)
+        b = lbm.Simulation(p, obst)
+        av_a = np.concatenate([a.run(steps), a.run(131)])
+        av_b = np.concatenate([b.run(steps), b.run(131)])
+        assert np.array_equal(av_a, av_b), steps
+        assert np.array_equal(bits(a.local_cells()), bits(b.local_cells())), steps
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_8x3", "rand_64x48", "walls_40x24", "wide_256x8", "tall_8x256",
+                                  "synth_512x512_t100", "1024x1024_t200"])
+def test_lds_staged_kernel_same_results(lbm, oracle, digests, name):
+    """LBM_FLAG_KERNEL_LDS: the LDS-tiled form of the step kernel (aligned loads, x+-1 neighbours and
+    the obstacle bitfield through LDS) must give the same bits as the direct-load form."""
+    p, obst, free = load_case(lbm, digests, name)
+    steps = min(p.max_iters, 150)
+    s = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_KERNEL_LDS)
+    assert "lds" in s.partition.describe()["kernel"]
+    av = s.run(steps)
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("nx,ny", [(4, 3), (12, 7), (36, 5), (1028, 6), (2048, 3)])
+def test_lds_staged_kernel_odd_shapes(lbm, oracle, nx, ny):
+    p = lbm.Params(nx, ny, 30, 4, 0.1, 0.01, 1.4)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.1, nx * 31 + ny, False)
+    if obst.all():
+        obst[0, 0] = 0
+    s = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_KERNEL_LDS | lbm._capi.FLAG_NT_STORES)
+    s.run(30)
+    ref_cells, _, _ = oracle.run(p, obst, 30)
+    assert np.array_equal(bits(s.local_cells()), bits(ref_cells))
+    s.close()
+
+
+def test_lds_staged_kernel_in_a_ring(lbm, oracle, digests):
+    p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO | lbm._capi.FLAG_KERNEL_LDS, exchange="rccl")
+    sim.run(40)
+    ref_cells, _, _ = oracle.run(p, obst, 40, nthreads=4)
+    assert np.array_equal(bits(sim.local_cells()), bits(ref_cells))
+    sim.close()
