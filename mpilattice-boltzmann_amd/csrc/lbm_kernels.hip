@@ -73,23 +73,8 @@ struct StepArgs {
   int* counter;                // index of the next entry of sums
 };
 
-// Kernel variants (template parameter V, bit set):
-constexpr int kNtStores = 1;   // non-temporal stores of the destination grid
-constexpr int kNtLoads = 2;    // non-temporal loads of the source grid            (tuning experiment)
-constexpr int kXcdRemap = 4;   // blocks of one XCD work on one contiguous eighth   (tuning experiment)
-
-template <int V>
-__device__ __forceinline__ f4 load4(const float* p)
-{
-  if (V & kNtLoads) return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
-  return *reinterpret_cast<const f4*>(p);
-}
-template <int V>
-__device__ __forceinline__ f4 load4u(const float* p)
-{
-  if (V & kNtLoads) return __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p));
-  return *reinterpret_cast<const f4u*>(p);
-}
+__device__ __forceinline__ f4 load4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ f4 load4u(const float* p) { return *reinterpret_cast<const f4u*>(p); }
 
 template <bool NT>
 __device__ __forceinline__ void store4(float* p, f4 v)
@@ -118,6 +103,11 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 d
   for (int w = 1; w < kBlock / 64; ++w) t += lds[w];
   return t;
 }
+
+// Block 0 of every step launch does no lattice work: it folds the PREVIOUS
+// step's per-block sums into sums[counter++] (d2q9-bgk.c:367) while the other blocks stream, so the
+// fold's latency (a dependent load + two barriers) is off the critical path of the tiny grids.
+__device__ __forceinline__ void fold_previous(const StepArgs& a, double* red);
 
 // One cell: moments, equilibrium, relaxation in the reference's operation order (d2q9-bgk.c:546-666).
 // t[] = streamed-in populations, o[] = relaxed populations; returns sqrt(m^2)/rho in double (:667).
@@ -243,7 +233,7 @@ __device__ __forceinline__ double finish_quad(const StepArgs& a, int c, int y, i
 
 // Direct-load form: processes the 4 cells starting at partition-local cell index 4*quad
 // (nx % 4 == 0, so the four share a row).
-template <int V>
+template <bool NT>
 __device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
 {
   const int c = quad * kCellsPerLane;
@@ -255,15 +245,15 @@ __device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
 
   // pull (d2q9-bgk.c:530-538): aligned for x, dword-shifted for x-1 / x+1
   f4 p[9];
-  p[0] = load4<V>(r.here + x0);
-  p[2] = load4<V>(r.s2 + x0);
-  p[4] = load4<V>(r.n4 + x0);
-  p[1] = load4u<V>(r.here + ps + x0 - 1);
-  p[5] = load4u<V>(r.s5 + x0 - 1);
-  p[8] = load4u<V>(r.n8 + x0 - 1);
-  p[3] = load4u<V>(r.here + 3 * ps + x0 + 1);
-  p[6] = load4u<V>(r.s6 + x0 + 1);
-  p[7] = load4u<V>(r.n7 + x0 + 1);
+  p[0] = load4(r.here + x0);
+  p[2] = load4(r.s2 + x0);
+  p[4] = load4(r.n4 + x0);
+  p[1] = load4u(r.here + ps + x0 - 1);
+  p[5] = load4u(r.s5 + x0 - 1);
+  p[8] = load4u(r.n8 + x0 - 1);
+  p[3] = load4u(r.here + 3 * ps + x0 + 1);
+  p[6] = load4u(r.s6 + x0 + 1);
+  p[7] = load4u(r.n7 + x0 + 1);
   const uint32_t mword = a.mask[c >> 5];
   if (x0 == 0) {                       // x_w wraps to nx-1 (:529)
     p[1].x = r.here[ps + nx - 1];
@@ -276,7 +266,58 @@ __device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
     p[7].w = r.n7[0];
   }
   const uint32_t mbits = (mword >> (c & 31)) & 0xFu;
-  return finish_quad<(V & kNtStores) != 0>(a, c, y, x0, p, mbits);
+  return finish_quad<NT>(a, c, y, x0, p, mbits);
+}
+
+// One-cell-per-lane form: used for grids so small that a step is bound by the latency of one lane's
+// dependent instruction chain rather than by bandwidth (4x more lanes, each with a quarter of the
+// chain), and for row lengths that are not a multiple of 4.  `cell` = partition-local cell index.
+template <bool NT>
+__device__ __forceinline__ double step_cell(const StepArgs& a, int cell)
+{
+  const int y = cell / a.nx;
+  const int x = cell - y * a.nx;
+  const size_t ps = a.ps;
+  const int nx = a.nx;
+  const RowPtrs r = source_rows(a, y);
+  const int xe = (x + 1 >= nx) ? x + 1 - nx : x + 1;                   // :527-528
+  const int xw = (x == 0) ? nx - 1 : x - 1;                             // :529
+  float t[9], o[9];
+  t[0] = r.here[x];            t[1] = r.here[ps + xw];      t[2] = r.s2[x];      // :530-532
+  t[3] = r.here[3 * ps + xe];  t[4] = r.n4[x];              t[5] = r.s5[xw];     // :533-535
+  t[6] = r.s6[xe];             t[7] = r.n7[xe];             t[8] = r.n8[xw];     // :536-538
+  const bool blocked = (a.mask[cell >> 5] >> (cell & 31)) & 1u;
+  const double term = relax_cell(t, a.omega, o);
+  float out[9];
+  out[0] = blocked ? t[0] : o[0];                                       // bounce-back :687-695
+  out[1] = blocked ? t[3] : o[1];
+  out[2] = blocked ? t[4] : o[2];
+  out[3] = blocked ? t[1] : o[3];
+  out[4] = blocked ? t[2] : o[4];
+  out[5] = blocked ? t[7] : o[5];
+  out[6] = blocked ? t[8] : o[6];
+  out[7] = blocked ? t[5] : o[7];
+  out[8] = blocked ? t[6] : o[8];
+  if (y == a.accel_row && !blocked && out[3] - a.accel_w1 > 0.0f && out[6] - a.accel_w2 > 0.0f &&
+      out[7] - a.accel_w2 > 0.0f) {                                     // next step's accelerate_flow :457-469
+    out[1] += a.accel_w1; out[5] += a.accel_w2; out[8] += a.accel_w2;
+    out[3] -= a.accel_w1; out[6] -= a.accel_w2; out[7] -= a.accel_w2;
+  }
+  float* d = a.dst + cell;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (NT) __builtin_nontemporal_store(out[k], d + k * ps);
+    else d[k * ps] = out[k];
+  }
+  if (a.send_south != nullptr && y == 0) {
+    float* s = a.send_south + kHaloGuard + x;
+    s[0] = out[4]; s[a.nxp] = out[7]; s[2 * a.nxp] = out[8];
+  }
+  if (a.send_north != nullptr && y == a.nyl - 1) {
+    float* s = a.send_north + kHaloGuard + x;
+    s[0] = out[2]; s[a.nxp] = out[5]; s[2 * a.nxp] = out[6];
+  }
+  return blocked ? 0.0 : term;
 }
 
 // LDS-staged form (LBM_FLAG_KERNEL_LDS), the tiling BASELINE.json's north_star sentence describes:
@@ -307,15 +348,15 @@ __device__ __forceinline__ double step_quad_lds(const StepArgs& a, int quad, boo
   if (tid <= kBlock / 8 && word0 + tid < a.mask_words) tile.mask[tid] = a.mask[word0 + tid];
   if (active) {
     const RowPtrs r = source_rows(a, y);
-    p[0] = load4<0>(r.here + x0);
-    p[1] = load4<0>(r.here + ps + x0);
-    p[2] = load4<0>(r.s2 + x0);
-    p[3] = load4<0>(r.here + 3 * ps + x0);
-    p[4] = load4<0>(r.n4 + x0);
-    p[5] = load4<0>(r.s5 + x0);
-    p[6] = load4<0>(r.s6 + x0);
-    p[7] = load4<0>(r.n7 + x0);
-    p[8] = load4<0>(r.n8 + x0);
+    p[0] = load4(r.here + x0);
+    p[1] = load4(r.here + ps + x0);
+    p[2] = load4(r.s2 + x0);
+    p[3] = load4(r.here + 3 * ps + x0);
+    p[4] = load4(r.n4 + x0);
+    p[5] = load4(r.s5 + x0);
+    p[6] = load4(r.s6 + x0);
+    p[7] = load4(r.n7 + x0);
+    p[8] = load4(r.n8 + x0);
     tile.w[0][tid + 1] = p[1].w; tile.w[1][tid + 1] = p[5].w; tile.w[2][tid + 1] = p[8].w;
     tile.e[0][tid + 1] = p[3].x; tile.e[1][tid + 1] = p[6].x; tile.e[2][tid + 1] = p[7].x;
     // halo columns of the tile row (only the block's first / last lane have no neighbour lane) and
@@ -359,61 +400,70 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel_lds(const StepArgs a)
 {
   __shared__ double red[kBlock / 64];
   __shared__ LdsTile tile;
-  if (blockIdx.x == 0 && a.n_prev > 0) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s += a.prev_partials[i];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) {
-      const int t = *a.counter;
-      a.sums[t] = s;
-      *a.counter = t + 1;
-    }
-  }
+  if (blockIdx.x == 0) { fold_previous(a, red); return; }
+  const int wblock = blockIdx.x - 1;   // work block index
   double acc = 0.0;
   const int n1 = a.quad_end - a.quad_begin;
   for (int i = 0; i < a.iters; ++i) {
-    const int r0 = (blockIdx.x * a.iters + i) * kBlock;      // block-uniform: every lane reaches the barriers
+    const int r0 = (wblock * a.iters + i) * kBlock;          // block-uniform: every lane reaches the barriers
     if (r0 >= n1) break;
     const int r = r0 + threadIdx.x;
     acc += step_quad_lds<NT>(a, a.quad_begin + r, r < n1, (a.quad_begin + r0) * kCellsPerLane, tile);
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[blockIdx.x] = acc;
+  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
 }
 
-// The fused streaming-pull step.  Grid: ceil(#quads / (256*iters)) blocks of 256 lanes; block b
-// owns `iters` consecutive 1024-cell chunks.
-template <int V>
+// The fused streaming-pull step.  Grid: ceil(#quads / (256*iters)) work blocks of 256 lanes (block b
+// owns `iters` consecutive 1024-cell chunks) after one fold block (block 0, dispatched first).
+template <bool NT>
 __global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
 {
   __shared__ double red[kBlock / 64];
-  // logical block: with kXcdRemap the blocks that share an XCD (dispatch deals blocks round-robin
-  // over the 8 XCDs: b and b+8 share one) take one contiguous eighth of the grid each
-  const int lblock = (V & kXcdRemap) ? static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
-                                     : static_cast<int>(blockIdx.x);
-
-  // block 0: fold the previous step's per-block sums into sums[counter++] (d2q9-bgk.c:367)
-  if (blockIdx.x == 0 && a.n_prev > 0) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s += a.prev_partials[i];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) {
-      const int t = *a.counter;
-      a.sums[t] = s;
-      *a.counter = t + 1;
-    }
-  }
-
+  if (blockIdx.x == 0) { fold_previous(a, red); return; }
+  const int wblock = blockIdx.x - 1;   // work block index
   double acc = 0.0;
   const int n1 = a.quad_end - a.quad_begin;
   const int n2 = a.quad_end2 > a.quad_begin2 ? a.quad_end2 - a.quad_begin2 : 0;
-  const int base = lblock * a.iters * kBlock + threadIdx.x;
+  const int base = wblock * a.iters * kBlock + threadIdx.x;
   for (int i = 0; i < a.iters; ++i) {
     const int r = base + i * kBlock;
-    if (r < n1 + n2) acc += step_quad<V>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
+    if (r < n1 + n2) acc += step_quad<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[lblock] = acc;
+  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
+}
+
+// One cell per lane; the unit ranges of StepArgs are cell ranges here.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) lbm_step_kernel_narrow(const StepArgs a)
+{
+  __shared__ double red[kBlock / 64];
+  if (blockIdx.x == 0) { fold_previous(a, red); return; }
+  const int wblock = blockIdx.x - 1;   // work block index
+  double acc = 0.0;
+  const int n1 = a.quad_end - a.quad_begin;
+  const int n2 = a.quad_end2 > a.quad_begin2 ? a.quad_end2 - a.quad_begin2 : 0;
+  const int base = wblock * a.iters * kBlock + threadIdx.x;
+  for (int i = 0; i < a.iters; ++i) {
+    const int r = base + i * kBlock;
+    if (r < n1 + n2) acc += step_cell<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
+}
+
+__device__ __forceinline__ void fold_previous(const StepArgs& a, double* red)
+{
+  if (a.n_prev <= 0) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s += a.prev_partials[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const int t = *a.counter;
+    a.sums[t] = s;
+    *a.counter = t + 1;
+  }
 }
 
 // Folds the last step's partials after the loop.
@@ -553,7 +603,6 @@ struct lbm_ctx {
   bool self_periodic = true;
   int accel_row = -1;
   bool nt_stores = false;
-  int tune_variant = 0;      // LBM_TUNE_VARIANT: kNtLoads | kXcdRemap experiments
   size_t ncells = 0, ps = 0, grid_floats = 0;
   float* grid_alloc[2] = {nullptr, nullptr};
   float* grid[2] = {nullptr, nullptr};       // plane 0 row 0 (after the front guard)
@@ -561,6 +610,7 @@ struct lbm_ctx {
   uint32_t* mask = nullptr;
   int mask_words = 0;
   bool lds_kernel = false;   // LBM_FLAG_KERNEL_LDS
+  int lane_cells = kCellsPerLane;   // cells per lane: 4 (vector form) or 1 (narrow form: tiny grids, nx % 4 != 0)
   int nxp = 0;
   float* halo_alloc = nullptr;
   float* send[2] = {nullptr, nullptr};
@@ -649,22 +699,16 @@ StepArgs base_args(lbm_ctx* c, bool accel_next)
 
 void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 {
-  if (c->lds_kernel && a.quad_begin2 >= a.quad_end2) {
-    if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel_lds<true>, dim3(blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL(lbm_step_kernel_lds<false>, dim3(blocks), dim3(kBlock), 0, s, a);
-    return;
-  }
-  int v = (c->nt_stores ? kNtStores : 0) | c->tune_variant;
-  if ((v & kXcdRemap) && (blocks % 8 != 0 || blocks < 64)) v &= ~kXcdRemap;
-  switch (v) {
-    case 0: hipLaunchKernelGGL(lbm_step_kernel<0>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    case 1: hipLaunchKernelGGL(lbm_step_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(lbm_step_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(lbm_step_kernel<3>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(lbm_step_kernel<4>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(lbm_step_kernel<5>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(lbm_step_kernel<6>, dim3(blocks), dim3(kBlock), 0, s, a); break;
-    default: hipLaunchKernelGGL(lbm_step_kernel<7>, dim3(blocks), dim3(kBlock), 0, s, a); break;
+  const dim3 grid(blocks + 1), block(kBlock);   // + the fold block
+  if (c->lane_cells == 1) {
+    if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel_narrow<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(lbm_step_kernel_narrow<false>, grid, block, 0, s, a);
+  } else if (c->lds_kernel && a.quad_begin2 >= a.quad_end2) {
+    if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel_lds<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(lbm_step_kernel_lds<false>, grid, block, 0, s, a);
+  } else {
+    if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(lbm_step_kernel<false>, grid, block, 0, s, a);
   }
 }
 
@@ -694,7 +738,7 @@ constexpr int kGraphSteps = 64;   // even: the source/destination roles and the 
 // One whole-grid step of a self-contained domain: launch + state flip (d2q9-bgk.c:345-378).
 void full_step(lbm_ctx* c, bool accel_next, hipStream_t s)
 {
-  const long long quads = static_cast<long long>(c->p.nx / kCellsPerLane) * c->nyl;
+  const long long quads = static_cast<long long>(c->p.nx / c->lane_cells) * c->nyl;
   StepArgs a = base_args(c, accel_next);
   a.quad_begin = 0; a.quad_end = static_cast<int>(quads);
   a.quad_begin2 = a.quad_end2 = 0;
@@ -736,7 +780,7 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
 {
   if (!out || !p || !obstacles_rows) { lbm_internal::set_error("lbm_create: null argument"); return 1; }
   *out = nullptr;
-  if (p->nx < 4 || p->nx % 4 != 0) { lbm_internal::set_error("lbm_create: nx must be a positive multiple of 4"); return 1; }
+  if (p->nx < 1) { lbm_internal::set_error("lbm_create: nx must be positive"); return 1; }
   if (p->ny < 3) { lbm_internal::set_error("lbm_create: ny must be >= 3 (accelerate_flow works on row ny-2, d2q9-bgk.c:449)"); return 1; }
   if (ny_local < 1 || y0 < 0 || y0 + ny_local > p->ny) { lbm_internal::set_error("lbm_create: partition rows out of range"); return 1; }
   if (free_cells <= 0) { lbm_internal::set_error("lbm_create: free_cells must be positive"); return 1; }
@@ -768,8 +812,11 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   c->nt_stores = state_bytes > (192u << 20);
   if (flags & LBM_FLAG_NT_STORES) c->nt_stores = true;
   if (flags & LBM_FLAG_NO_NT_STORES) c->nt_stores = false;
-  c->tune_variant = tune_env("LBM_TUNE_VARIANT", 0) & (kNtLoads | kXcdRemap);
-  c->lds_kernel = (flags & LBM_FLAG_KERNEL_LDS) != 0;
+  // narrow form for latency-bound grids (measured cross-over) and for nx % 4 != 0
+  // (128x128: 3.5 vs 4.4 us/step, 256x256: 4.1 vs 4.6, 512x512: 7.3 vs 6.2 -> cross-over at 64 K cells)
+  const size_t narrow_max = static_cast<size_t>(tune_env("LBM_TUNE_NARROW_MAX", 65536));
+  c->lane_cells = (p->nx % kCellsPerLane != 0 || c->ncells <= narrow_max) ? 1 : kCellsPerLane;
+  c->lds_kernel = (flags & LBM_FLAG_KERNEL_LDS) != 0 && c->lane_cells == kCellsPerLane;
   // hipGraph replay of 64-step blocks is opt-in: measured on MI355X it changes nothing (128x128:
   // 4.47 vs 4.33 us/step) because even the smallest grids are bound by the device-side kernel
   // boundary + kernel latency, not by the host's launch rate
@@ -818,7 +865,7 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   c->send[0] = c->halo_alloc; c->send[1] = c->halo_alloc + hb;
   c->recv[0] = c->halo_alloc + 2 * hb; c->recv[1] = c->halo_alloc + 3 * hb;
   // launch geometry + partial buffers
-  const long long qrow = p->nx / kCellsPerLane;
+  const long long qrow = p->nx / c->lane_cells;
   const long long qfull = qrow * ny_local;
   c->iters_full = pick_iters(qfull);
   c->n_part_full = blocks_for(qfull, c->iters_full);
@@ -992,7 +1039,7 @@ int lbm_step_interior(lbm_ctx* c, void* stream)
   if (!c) { lbm_internal::set_error("lbm_step_interior: null context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_step_interior: no steps left; call lbm_step_prepare"); return 1; }
   hipStream_t s = pick_stream(c, stream);
-  const int qrow = c->p.nx / kCellsPerLane;
+  const int qrow = c->p.nx / c->lane_cells;
   StepArgs a = base_args(c, c->run_done + 1 < c->run_steps);
   a.quad_begin = qrow; a.quad_end = qrow * (c->nyl - 1);
   a.quad_begin2 = a.quad_end2 = 0;
@@ -1013,7 +1060,7 @@ int lbm_step_boundary(lbm_ctx* c, void* stream)
   if (!c) { lbm_internal::set_error("lbm_step_boundary: null context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_step_boundary: no steps left; call lbm_step_prepare"); return 1; }
   hipStream_t s = pick_stream(c, stream);
-  const int qrow = c->p.nx / kCellsPerLane;
+  const int qrow = c->p.nx / c->lane_cells;
   StepArgs a = base_args(c, c->run_done + 1 < c->run_steps);
   a.quad_begin = 0; a.quad_end = qrow;
   if (c->nyl > 1) { a.quad_begin2 = qrow * (c->nyl - 1); a.quad_end2 = qrow * c->nyl; }
@@ -1079,8 +1126,9 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
-    else std::snprintf(kernel_name, len, "lbm_step_kernel<%d>", (c->nt_stores ? kNtStores : 0) | c->tune_variant);
+    if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
+    else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
+    else std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");
   }
   if (cells_per_launch) *cells_per_launch = static_cast<long long>(c->ncells);
   if (state_bytes) *state_bytes = static_cast<long long>(2 * 9 * c->ncells * sizeof(float) + c->ncells / 8);

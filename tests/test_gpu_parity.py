@@ -42,8 +42,17 @@ def load_case(lbm, digests, name):
     return p, obst, free
 
 
+@pytest.fixture(params=["vector", "auto"])
+def kernel_form(request, monkeypatch):
+    """"vector": force the 4-cells-per-lane kernel on every size; "auto": the library's choice (one
+    cell per lane up to 64 K cells)."""
+    if request.param == "vector":
+        monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", SMALL)
-def test_state_bit_exact_and_files_match_reference_digests(lbm, oracle, digests, tmp_path, name):
+def test_state_bit_exact_and_files_match_reference_digests(lbm, oracle, digests, tmp_path, kernel_form, name):
     p, obst, free = load_case(lbm, digests, name)
     sim = lbm.Simulation(p, obst)
     av = sim.run()
@@ -88,7 +97,7 @@ def test_cli_on_shipped_decks(lbm, digests, tmp_path, name):
     assert np.allclose(av[steps], ref, rtol=4e-3 if name == "1024x1024" else 5e-4)
 
 
-def test_repeated_runs_equal_one_run(lbm, digests):
+def test_repeated_runs_equal_one_run(lbm, digests, kernel_form):
     p, obst, _ = load_case(lbm, digests, "rand_64x48")
     a = lbm.Simulation(p, obst)
     av_a = a.run(25)
@@ -120,7 +129,7 @@ def test_store_policy_does_not_change_results(lbm, oracle, digests, flags):
     s.close()
 
 
-def test_set_cells_random_state(lbm, oracle):
+def test_set_cells_random_state(lbm, oracle, kernel_form):
     rng = np.random.default_rng(11)
     p = lbm.Params(48, 20, 8, 4, 0.1, 0.02, 1.6)
     obst = lbm.synthetic_obstacles(48, 20, 0.08, 9, False)
@@ -136,7 +145,7 @@ def test_set_cells_random_state(lbm, oracle):
 
 
 @pytest.mark.parametrize("nx,ny", [(4, 3), (8, 3), (4, 64), (2048, 3), (12, 7), (36, 5), (1028, 6)])
-def test_odd_shapes(lbm, oracle, nx, ny):
+def test_odd_shapes(lbm, oracle, kernel_form, nx, ny):
     """nx only needs to be a multiple of 4 here (the reference silently needs 8, d2q9-bgk.c:453,520);
     rows of any count >= 3; tiles that straddle rows."""
     p = lbm.Params(nx, ny, 30, 4, 0.1, 0.01, 1.4)
@@ -176,7 +185,7 @@ lbm_SOUTH, lbm_NORTH = 0, 1
 
 @pytest.mark.parametrize("case,size", [("rand_64x48", 2), ("rand_64x48", 3), ("rand_64x48", 5), ("walls_40x24", 8),
                                        ("tall_8x256", 64), ("wide_256x8", 2), ("synth_512x512_t100", 8)])
-def test_row_partitioned_stepping_equals_single_partition(lbm, oracle, digests, case, size):
+def test_row_partitioned_stepping_equals_single_partition(lbm, oracle, digests, kernel_form, case, size):
     """Split-phase C ABI (interior / boundary / halo buffers) with `size` partitions of one grid on
     one GPU, exchanged by device copies: must be bit-identical to the single-partition run, and the
     summed per-step tot_u must match."""
@@ -237,7 +246,7 @@ def test_full_size_8192_properties_and_short_parity(lbm, oracle):
 
 
 @pytest.mark.parametrize("case", ["rand_64x48", "walls_40x24", "synth_512x512_t100"])
-def test_rccl_ring_of_one_rank(lbm, oracle, digests, case):
+def test_rccl_ring_of_one_rank(lbm, oracle, digests, kernel_form, case):
     """The native RCCL step loop (liblbm_d2q9_rccl.so) on a 1-rank ring: the rank sends its edge rows
     to itself through RCCL on the side stream, exactly the reference's 1-rank behaviour
     (d2q9-bgk.c:245-247).  Exercises communicator set-up, the event ordering between the exchange
@@ -275,7 +284,7 @@ def test_distributed_world_of_one_over_nccl(lbm, oracle, digests, tmp_path, exch
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
-def test_graph_replay_equals_direct_launches(lbm, digests):
+def test_graph_replay_equals_direct_launches(lbm, digests, kernel_form):
     """With LBM_FLAG_GRAPH lbm_run replays 64-step hipGraphs; by default it launches every step.
     Both must give the same bits, for step counts around the block size and across calls."""
     p, obst, _ = load_case(lbm, digests, "rand_64x48")
@@ -291,9 +300,10 @@ def test_graph_replay_equals_direct_launches(lbm, digests):
 
 @pytest.mark.parametrize("name", ["tiny_8x3", "rand_64x48", "walls_40x24", "wide_256x8", "tall_8x256",
                                   "synth_512x512_t100", "1024x1024_t200"])
-def test_lds_staged_kernel_same_results(lbm, oracle, digests, name):
+def test_lds_staged_kernel_same_results(lbm, oracle, digests, monkeypatch, name):
     """LBM_FLAG_KERNEL_LDS: the LDS-tiled form of the step kernel (aligned loads, x+-1 neighbours and
     the obstacle bitfield through LDS) must give the same bits as the direct-load form."""
+    monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
     p, obst, free = load_case(lbm, digests, name)
     steps = min(p.max_iters, 150)
     s = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_KERNEL_LDS)
@@ -307,7 +317,8 @@ def test_lds_staged_kernel_same_results(lbm, oracle, digests, name):
 
 
 @pytest.mark.parametrize("nx,ny", [(4, 3), (12, 7), (36, 5), (1028, 6), (2048, 3)])
-def test_lds_staged_kernel_odd_shapes(lbm, oracle, nx, ny):
+def test_lds_staged_kernel_odd_shapes(lbm, oracle, monkeypatch, nx, ny):
+    monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
     p = lbm.Params(nx, ny, 30, 4, 0.1, 0.01, 1.4)
     obst = lbm.synthetic_obstacles(nx, ny, 0.1, nx * 31 + ny, False)
     if obst.all():
@@ -319,10 +330,48 @@ def test_lds_staged_kernel_odd_shapes(lbm, oracle, nx, ny):
     s.close()
 
 
-def test_lds_staged_kernel_in_a_ring(lbm, oracle, digests):
+def test_lds_staged_kernel_in_a_ring(lbm, oracle, digests, monkeypatch):
+    monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
     p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
     sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO | lbm._capi.FLAG_KERNEL_LDS, exchange="rccl")
     sim.run(40)
     ref_cells, _, _ = oracle.run(p, obst, 40, nthreads=4)
     assert np.array_equal(bits(sim.local_cells()), bits(ref_cells))
     sim.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(1, 4), (2, 3), (5, 3), (7, 9), (18, 6), (30, 11), (1023, 4), (257, 33)])
+def test_row_lengths_not_multiple_of_four(lbm, oracle, nx, ny):
+    """Any nx works (one-cell-per-lane form); the reference silently needs nx % 8 == 0 (d2q9-bgk.c:453,520)."""
+    p = lbm.Params(nx, ny, 25, 4, 0.1, 0.01, 1.6)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.1, nx * 131 + ny, False)
+    if obst.all():
+        obst[0, 0] = 0
+    s = lbm.Simulation(p, obst)
+    assert "narrow" in s.partition.describe()["kernel"]
+    av = s.run(25)
+    ref_cells, _, ref_exact = oracle.run(p, obst, 25)
+    assert np.array_equal(bits(s.local_cells()), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["rand_64x48", "walls_40x24", "accelrow_blocked_32x16", "strongaccel_32x16", "synth_512x512_t100"])
+def test_narrow_kernel_on_regular_decks(lbm, oracle, digests, monkeypatch, name):
+    monkeypatch.setenv("LBM_TUNE_NARROW_MAX", str(1 << 30))
+    p, obst, free = load_case(lbm, digests, name)
+    steps = min(p.max_iters, 150)
+    s = lbm.Simulation(p, obst)
+    assert "narrow" in s.partition.describe()["kernel"]
+    av = s.run(steps)
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    # and in a ring (interior / boundary launches, halo messages written by scalar stores)
+    ring = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    av2 = ring.run(steps)
+    assert np.array_equal(bits(ring.local_cells()), bits(ref_cells))
+    assert np.max(np.abs(av2 - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    ring.close()

@@ -144,7 +144,7 @@ def test_create_validates_arguments(lbm):
     lib = lbm.load_library()
     ctx = C.c_void_p()
     obst = np.zeros((8, 16), np.int32)
-    for kw, msg in [(dict(nx=18), "multiple of 4"), (dict(ny=2), "ny must be >= 3")]:
+    for kw, msg in [(dict(nx=0), "nx must be positive"), (dict(ny=2), "ny must be >= 3")]:
         p = dict(nx=16, ny=8); p.update(kw)
         cp = lbm._capi.CParams(p["nx"], p["ny"], 1, 4, 0.1, 0.005, 1.0)
         rc = lib.lbm_create(C.byref(ctx), C.byref(cp), 100, lbm._capi.as_int_ptr(obst), 0, p["ny"], 0, 0)
