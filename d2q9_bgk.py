@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""d2q9_bgk.py <paramfile> <obstaclefile> — the reference's command-line contract on 1..N GPUs.
+
+Single GPU:   python d2q9_bgk.py input.params obstacles.dat          (same as bin/d2q9-bgk)
+N GPUs:       python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+                  --master-port P d2q9_bgk.py input.params obstacles.dat
+where it plays the role of `mpirun -np N ./d2q9-bgk` (reference `mpi_submit:63`): rows are
+partitioned by the reference's rule (`d2q9-bgk.c:834-862`), halos travel over RCCL, rank 0 prints
+the five stdout lines (`:411-415`) and writes final_state.dat / av_vels.dat into the cwd.
+"""
+import os
+import resource
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def die(message: str) -> None:
+    """`die()` of the reference (`d2q9-bgk.c:1145-1151`)."""
+    sys.stderr.write(f"Error in {os.path.basename(__file__)}:\n{message}\n")
+    sys.stderr.flush()
+    sys.exit(1)
+
+
+def main(argv) -> int:
+    if len(argv) != 3:                                                     # :197-200, :1153-1157
+        sys.stderr.write(f"Usage: {argv[0]} <paramfile> <obstaclefile>\n")
+        return 1
+    import mpilattice_boltzmann_amd as lbm
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        params = lbm.read_params(argv[1])
+        obstacles, _ = lbm.read_obstacles(argv[2], params.nx, params.ny)
+    except lbm.LbmError as e:
+        die(str(e))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    try:
+        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1,
+                             exchange=os.environ.get("LBM_EXCHANGE", "rccl"))
+    except lbm.LbmError as e:
+        die(str(e))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tic = time.time()                                                      # :278-279
+    av_vels = sim.run(params.max_iters)                                    # :315-396
+    torch.cuda.synchronize()
+    toc = time.time()                                                      # :397-398
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    cells = sim.gather_cells()                                             # rank 0 gets the whole grid
+    if rank == 0:
+        print("==done==")                                                  # :411-415
+        print("Reynolds number:\t\t%.12E" % sim.reynolds(cells))
+        print("Elapsed time:\t\t\t%.6f (s)" % (toc - tic))
+        print("Elapsed user CPU time:\t\t%.6f (s)" % ru.ru_utime)
+        print("Elapsed system CPU time:\t%.6f (s)" % ru.ru_stime)
+        mlups = params.nx * params.ny * params.max_iters / (toc - tic) / 1e6
+        print("MLUPS:\t\t\t\t%.1f (%d GPU%s)" % (mlups, world, "" if world == 1 else "s"))
+        if not os.environ.get("LBM_NO_OUTPUT"):                            # :419-421
+            sim.write_values(av_vels, ".", cells)
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -17,7 +17,7 @@ LIB_RCCL = os.path.join(PKG, "lib", "liblbm_d2q9_rccl.so")
 CLI = os.path.join(PKG, "bin", "d2q9-bgk")
 
 # -ffp-contract=off: keep the reference's unfused float arithmetic (bit parity with gcc -std=c99).
-COMMON = ["-O3", "-ffp-contract=off", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+COMMON = ["-O3", "-ffp-contract=off", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
 
 def _hipcc() -> str:

@@ -375,3 +375,23 @@ def test_narrow_kernel_on_regular_decks(lbm, oracle, digests, monkeypatch, name)
     assert np.array_equal(bits(ring.local_cells()), bits(ref_cells))
     assert np.max(np.abs(av2 - ref_exact) / ref_exact) < AV_EXACT_RTOL
     ring.close()
+
+
+def test_python_cli_under_torchrun_world_of_one(lbm, digests, tmp_path):
+    """d2q9_bgk.py (the N-GPU front end with the reference's CLI contract) launched the way the
+    N > 1 case is, with one rank: same stdout lines and byte-identical final_state.dat."""
+    import sys
+    from conftest import ROOT
+    name = "128x256_t2000"
+    ppath, opath = deck_paths(name, digests)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    i = out.index("==done==")
+    assert out[i + 1] == digests[name]["reynolds_line"]
+    assert out[i + 2].startswith("Elapsed time:\t\t\t")
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
+    assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)

@@ -127,6 +127,18 @@ def test_writers_and_epilogue_match_the_oracle(lbm, oracle, tmp_path):
     oracle.write_av_vels(b, av)
     assert open(a, "rb").read() == open(b, "rb").read()
     assert open(a).readline() == "0:\t%.12E\n" % av[0]
+    # special values, many rows (several formatting blocks and threads), every exponent width
+    big = lbm.Params(64, 1200, 3, 7, 0.1, 0.005, 1.3)
+    cb = (rng.random((1200, 64, 9), dtype=np.float32) * np.float32(10.0) ** rng.integers(-30, 20, (1200, 64, 1))).astype(np.float32)
+    cb[0, 0] = 0.0                      # rho = 0 -> nan / inf columns
+    cb[0, 1] = [1e-45, 0, 0, 0, 0, 0, 0, 0, 0]   # denormal
+    cb[0, 2] = [-1.0, 0.5, 0, 0, 0, 0, 0, 0, 0]
+    cb[1, 0, 1] = np.inf
+    ob = (rng.random((1200, 64)) < 0.1).astype(np.int32)
+    ob[0, :3] = 0
+    lbm.write_final_state(a, big, cb, ob, displ=5)
+    oracle.write_final_state(b, big, cb, ob, displ=5)
+    assert open(a, "rb").read() == open(b, "rb").read()
     assert lbm.av_velocity_host(p, cells, obst) == oracle.av_velocity_sum(p, cells, obst)
     assert lbm.reynolds(p, 0.0123) == oracle.reynolds(p, 0.0123)
 
