@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="8192x8192", help="NXxNY of the synthetic deck (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ring", action="store_true",
+                    help="N=1 only: run the row-partitioned code path on a 1-rank ring (the rank exchanges with itself over RCCL)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="N>1 halo exchange: native RCCL loop (liblbm_d2q9_rccl.so) or torch.distributed P2P ops")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the 1-core port sample")
@@ -144,22 +146,21 @@ def main() -> None:
 
     import torch
     import mpilattice_boltzmann_amd as lbm
-    if rank == 0:
-        lbm.build()
-    nx, ny = (int(v) for v in args.workload.lower().split("x"))
-    params = lbm.Params(nx, ny, args.steps, 10, 0.1, 0.005, 1.85)
-    obstacles = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
-
+    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        lbm.build()                                       # no-op when lib/ is current; other ranks wait below
+    if dist is not None:
         dist.barrier()
-    else:
-        torch.cuda.set_device(local_rank)
     lbm.load_library()
-    sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=args.exchange)
+    nx, ny = (int(v) for v in args.workload.lower().split("x"))
+    params = lbm.Params(nx, ny, args.steps, 10, 0.1, 0.005, 1.85)
+    obstacles = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
+    flags = lbm._capi.FLAG_FORCE_HALO if args.ring else 0
+    sim = lbm.Simulation(params, obstacles, device=local_rank, flags=flags, distributed=world > 1, exchange=args.exchange)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -188,7 +189,7 @@ def main() -> None:
         mlups = cells * args.steps / elapsed / 1e6
         # dominant kernel: the fused step kernel; average launch duration from HIP events on its stream
         avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
-        if world == 1:
+        if world == 1 and not args.ring:
             cells_per_launch = desc["cells_per_launch"]
         else:                                             # interior + boundary launch per step on this rank
             cells_per_launch = desc["cells_per_launch"] / 2.0
@@ -197,7 +198,7 @@ def main() -> None:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath))
-            if t.get("workload") == f"{nx}x{ny}" and world == 1:
+            if t.get("workload") == f"{nx}x{ny}" and world == 1 and not args.ring:
                 traffic = t.get("hbm_bytes_per_launch")
         out = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
@@ -205,7 +206,7 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny,
-                       "partitioning": "single GPU" if world == 1 else f"{world} row blocks, 1-row halo exchange (RCCL send/recv, {args.exchange} loop), one all-reduce after the loop"},
+                       "partitioning": ("single GPU" if not args.ring else "1-rank ring (self exchange over RCCL)") if world == 1 else f"{world} row blocks, 1-row halo exchange (RCCL send/recv, {args.exchange} loop), one all-reduce after the loop"},
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": desc["kernel"],
