@@ -466,18 +466,183 @@ __device__ __forceinline__ void fold_previous(const StepArgs& a, double* red)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Temporally blocked form for launch-latency-bound grids (the three small shipped decks).
+//
+// A step of a <= 256 K-cell grid takes less time to compute than a kernel boundary costs, so one
+// launch here advances the lattice by up to H steps (e.g. T = 16, H = 8: a 1024-lane block loads a 32x32
+// region (a 16x16 owned tile + an 8-cell ghost ring, periodic in x and y) into LDS, every lane keeps
+// ONE region cell for the whole launch, and sub-step s recomputes the region shrunk by s cells from
+// the LDS copy of sub-step s-1 (double-buffered, one barrier per sub-step).  Ghost cells are computed
+// redundantly by neighbouring blocks with the same arithmetic, so no block ever waits for another.
+// Per-step sum|u| is taken over owned cells only; accelerate_flow is applied to row ny-2 (ghost
+// copies too) between sub-steps exactly as between launches of the one-step kernels.  Results are
+// bit-identical to the one-step kernels (same relax_cell, same order of steps).
+// ------------------------------------------------------------------------------------------------
+// Geometry is a template parameter pair: T = owned tile edge, H = ghost ring = max steps per launch;
+// the region edge is R = T + 2H and the block has R*R lanes (<= 1024).
+constexpr int kMaxTileSteps = 8;
+
+template <int T, int H>
+struct TileGeom {
+  static constexpr int R = T + 2 * H;
+  static constexpr int lanes = R * R;
+  static constexpr int waves = (lanes + 63) / 64;
+  static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * lanes + sizeof(double) * H * waves;
+  static_assert(lanes <= 1024 && H <= kMaxTileSteps, "block too large");
+};
+
+struct TileArgs {
+  const float* src;
+  float* dst;
+  const uint32_t* mask;
+  size_t ps;
+  int nx, ny;
+  int tiles_x;                 // nx / T
+  int ksteps;                  // 1..H steps in this launch
+  float omega, accel_w1, accel_w2;
+  int accel_row;               // ny-2
+  int accel_last;              // apply accelerate_flow after the LAST sub-step too (another step follows)
+  double* partials_out;        // [ksteps][ntiles]
+  const double* prev_partials; // previous launch: [n_prev_vecs][n_prev]
+  int n_prev, n_prev_vecs;
+  double* sums;
+  int* counter;
+};
+
+template <int T, int H>
+__global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H)) lbm_tile_kernel(const TileArgs a)
+{
+  using G = TileGeom<T, H>;
+  constexpr int R = G::R, kLanes = G::lanes, kWaves = G::waves;
+  extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][9][lanes] floats, then reduction scratch
+  double* red = reinterpret_cast<double*>(lds + 2 * 9 * kLanes);    // [H][kWaves]
+  const int tid = threadIdx.x;
+
+  if (blockIdx.x == 0) {
+    // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
+    for (int v = 0; v < a.n_prev_vecs; ++v) {
+      double s = 0.0;
+      for (int i = tid; i < a.n_prev; i += kLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
+      s = wave_sum(s);
+      __syncthreads();
+      if ((tid & 63) == 0) red[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kWaves; ++w) t += red[w];
+        a.sums[*a.counter + v] = t;
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
+    return;
+  }
+
+  const int tile = blockIdx.x - 1;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int ry = tid / R, rx = tid - ry * R;
+  // global cell of this lane, periodic (d2q9-bgk.c:527-529 in x; :245-247 one-rank ring in y)
+  int gx = (tx * T - H + rx) % a.nx; if (gx < 0) gx += a.nx;
+  int gy = (ty * T - H + ry) % a.ny; if (gy < 0) gy += a.ny;
+  const int cell = gy * a.nx + gx;
+  const bool blocked = (a.mask[cell >> 5] >> (cell & 31)) & 1u;
+  const bool owned = rx >= H && rx < H + T && ry >= H && ry < H + T;
+  const bool on_accel_row = gy == a.accel_row;
+
+  float* bufA = lds;
+  float* bufB = lds + 9 * kLanes;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) bufA[k * kLanes + tid] = a.src[k * a.ps + cell];
+  __syncthreads();
+
+  double acc[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) acc[i] = 0.0;
+  float out[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out[k] = 0.0f;
+
+  const int k_total = a.ksteps;
+#pragma unroll 1
+  for (int s = 1; s <= k_total; ++s) {
+    // cells still needed after this sub-step: the owned tile expanded by (k_total - s)
+    const int e = k_total - s;
+    const bool active = rx >= H - e && rx < H + T + e && ry >= H - e && ry < H + T + e;
+    if (active) {
+      float t[9], o[9];
+      const int here = tid, south = tid - R, north = tid + R;                   // d2q9-bgk.c:530-538
+      t[0] = bufA[0 * kLanes + here];
+      t[1] = bufA[1 * kLanes + here - 1];
+      t[2] = bufA[2 * kLanes + south];
+      t[3] = bufA[3 * kLanes + here + 1];
+      t[4] = bufA[4 * kLanes + north];
+      t[5] = bufA[5 * kLanes + south - 1];
+      t[6] = bufA[6 * kLanes + south + 1];
+      t[7] = bufA[7 * kLanes + north + 1];
+      t[8] = bufA[8 * kLanes + north - 1];
+      const double term = relax_cell(t, a.omega, o);
+      out[0] = blocked ? t[0] : o[0];                                          // bounce-back :687-695
+      out[1] = blocked ? t[3] : o[1];
+      out[2] = blocked ? t[4] : o[2];
+      out[3] = blocked ? t[1] : o[3];
+      out[4] = blocked ? t[2] : o[4];
+      out[5] = blocked ? t[7] : o[5];
+      out[6] = blocked ? t[8] : o[6];
+      out[7] = blocked ? t[5] : o[7];
+      out[8] = blocked ? t[6] : o[8];
+      if (owned && !blocked) {
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+          if (i == s - 1) acc[i] = term;
+      }
+      // accelerate_flow of the following step (d2q9-bgk.c:457-469)
+      if (on_accel_row && !blocked && (s < k_total || a.accel_last) && out[3] - a.accel_w1 > 0.0f &&
+          out[6] - a.accel_w2 > 0.0f && out[7] - a.accel_w2 > 0.0f) {
+        out[1] += a.accel_w1; out[5] += a.accel_w2; out[8] += a.accel_w2;
+        out[3] -= a.accel_w1; out[6] -= a.accel_w2; out[7] -= a.accel_w2;
+      }
+      if (s < k_total) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) bufB[k * kLanes + tid] = out[k];
+      }
+    }
+    __syncthreads();
+    float* sw = bufA; bufA = bufB; bufB = sw;
+  }
+
+  if (owned) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.dst[k * a.ps + cell] = out[k];
+  }
+
+  // per-step sums over the owned cells of this tile: wave trees, then one lane per step over the waves
+  const int ntiles = gridDim.x - 1;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const double w = wave_sum(acc[i]);
+    if ((tid & 63) == 0) red[i * kWaves + (tid >> 6)] = w;
+  }
+  __syncthreads();
+  if (tid < k_total) {
+    double t = 0.0;
+    for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
+    a.partials_out[static_cast<size_t>(tid) * ntiles + tile] = t;
+  }
+}
+
 // Folds the last step's partials after the loop.
-__global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, double* sums, int* counter)
+__global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, int nvecs, double* sums, int* counter)
 {
   __shared__ double red[kBlock / 64];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += kBlock) s += partials[i];
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) {
-    const int t = *counter;
-    sums[t] = s;
-    *counter = t + 1;
+  for (int v = 0; v < nvecs; ++v) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) s += partials[static_cast<size_t>(v) * n + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) sums[*counter + v] = s;
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *counter += nvecs;
 }
 
 // accelerate_flow (d2q9-bgk.c:442-478) in place on one row: only needed before the first step of a run.
@@ -629,11 +794,16 @@ struct lbm_ctx {
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the step kernels of the last run
   int ev_launches = 0;
+  int ev_tile_launches = 0;
   bool ev_valid = false;
   // run state (split-phase and lbm_run)
   int run_steps = 0, run_done = 0;
   int parity = 0;            // partials buffer written by the current step
   int n_prev = 0;            // partial count of the previous step (0 = nothing to fold)
+  int n_prev_vecs = 1;       // ... and how many step vectors of that length the previous launch left (tile kernel: up to 8)
+  bool tile_kernel = false;  // lbm_run advances several steps per launch with lbm_tile_kernel (small grids)
+  int tile_T = 16, tile_H = 8;   // its geometry: owned tile edge, ghost ring = max steps per launch
+  int n_tiles = 0;
   float accel_w1 = 0.f, accel_w2 = 0.f;
 };
 
@@ -712,6 +882,13 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
   }
 }
 
+template <int T, int H>
+void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a)
+{
+  using G = TileGeom<T, H>;
+  lbm_tile_kernel<T, H><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+}
+
 int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
 {
   if (ensure_sums(c, n_steps)) return 1;
@@ -719,6 +896,7 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
   c->run_steps = n_steps;
   c->run_done = 0;
   c->n_prev = 0;
+  c->n_prev_vecs = 1;
   c->parity = 0;
   if (c->accel_row >= 0 && n_steps > 0) {
     // accelerate_flow of step 0 (d2q9-bgk.c:345-348); later steps get it from the kernel epilogue
@@ -748,6 +926,7 @@ void full_step(lbm_ctx* c, bool accel_next, hipStream_t s)
   a.n_prev = c->n_prev;
   launch_step(c, a, c->n_part_full, s);
   c->n_prev = c->n_part_full;
+  c->n_prev_vecs = 1;
   c->parity ^= 1;
   c->cur ^= 1;
 }
@@ -874,6 +1053,30 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   c->n_part_interior = qint > 0 ? blocks_for(qint, c->iters_interior) : 0;
   c->n_part_boundary = blocks_for(ny_local > 1 ? 2 * qrow : qrow, 1);
   c->partials_cap = std::max(c->n_part_full, c->n_part_interior + c->n_part_boundary) + 1;
+  // temporally blocked form: whole periodic grids whose edges are multiples of the tile edge and
+  // that are small enough to be launch-latency-bound (measured cross-over)
+  {
+    // geometry by size, measured on MI355X (us/step; one-step kernels 3.4 / 3.5 / 4.0 / 6.3):
+    //   128x128: <8,4> 1.6, <16,8> 1.9 | 128x256: <16,8> 2.0, <8,4> 2.1 | 256x256: <16,4> 2.5, <8,4> 2.9
+    //   512x512: <16,4> 5.2 | 1024x1024: slower than the one-step kernel (13.6)
+    const int by_size = c->ncells <= 16384 ? 84 : (c->ncells <= 32768 ? 168 : 164);
+    const int geom = tune_env("LBM_TUNE_TILE_GEOM", by_size);   // T*10 + H
+    c->tile_T = geom / 10; c->tile_H = geom % 10;
+    if (!((c->tile_T == 16 || c->tile_T == 8) && (c->tile_H == 8 || c->tile_H == 4))) { c->tile_T = 16; c->tile_H = 4; }
+  }
+  c->n_tiles = (p->nx % c->tile_T == 0 && ny_local % c->tile_T == 0) ? (p->nx / c->tile_T) * (ny_local / c->tile_T) : 0;
+  c->tile_kernel = self_periodic && c->n_tiles > 0 &&
+                   c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 262144));
+  if (c->tile_kernel) {
+    c->partials_cap = std::max(c->partials_cap, kMaxTileSteps * c->n_tiles + 1);
+    // up to 74 KB of dynamic LDS per block (two 9 x R x R float buffers): above the 64 KB default limit
+    {
+      using G168 = TileGeom<16, 8>;
+      auto* k168 = &lbm_tile_kernel<16, 8>;
+      HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k168), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(G168::lds_bytes)));
+    }
+  }
   for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->partials[i], sizeof(double) * c->partials_cap));
   HIP_TRY_C(hipMalloc(&c->counter, sizeof(int)));
   HIP_TRY_C(hipMemsetAsync(c->counter, 0, sizeof(int), c->stream));
@@ -918,7 +1121,33 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   if (begin_run(c, n_steps, s)) return 1;
-  for (int t = 0; t < n_steps;) {
+  int tile_launches = 0;
+  for (int t = 0; c->tile_kernel && t < n_steps;) {
+    // up to tile_H steps per launch (lbm_tile_kernel); every launch of such a run has this form
+    const int k = std::min(c->tile_H, n_steps - t);
+    TileArgs a{};
+    a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
+    a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx; a.ny = c->nyl; a.tiles_x = c->p.nx / c->tile_T;
+    a.ksteps = k;
+    a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
+    a.accel_row = c->accel_row; a.accel_last = (t + k < n_steps) ? 1 : 0;
+    a.partials_out = c->partials[c->parity];
+    a.prev_partials = c->partials[c->parity ^ 1];
+    a.n_prev = c->n_prev; a.n_prev_vecs = c->n_prev > 0 ? c->n_prev_vecs : 0;
+    a.sums = c->sums; a.counter = c->counter;
+    const dim3 grid(c->n_tiles + 1);
+    if (c->tile_T == 16 && c->tile_H == 8) launch_tile<16, 8>(grid, s, a);
+    else if (c->tile_T == 16) launch_tile<16, 4>(grid, s, a);
+    else if (c->tile_H == 8) launch_tile<8, 8>(grid, s, a);
+    else launch_tile<8, 4>(grid, s, a);
+    ++tile_launches;
+    c->n_prev = c->n_tiles; c->n_prev_vecs = k;
+    c->parity ^= 1;
+    c->cur ^= 1;
+    t += k;
+    if (t >= n_steps) c->ev_tile_launches = tile_launches;
+  }
+  for (int t = 0; !c->tile_kernel && t < n_steps;) {
     // launch-bound grids: replay a captured block of kGraphSteps steps while at least one more
     // step follows it (the last step of a run is launched directly: it must not accelerate)
     if (c->use_graph && c->n_prev > 0 && n_steps - t > kGraphSteps) {
@@ -932,11 +1161,12 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_end, s));
-  c->ev_launches = n_steps;
+  c->ev_launches = c->tile_kernel ? c->ev_tile_launches : n_steps;
   c->ev_valid = true;
-  hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->sums, c->counter);
+  hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
   HIP_TRY(hipGetLastError());
   c->n_prev = 0;
+  c->n_prev_vecs = 1;
   c->run_done = n_steps;
   if (av_vels) {
     std::vector<double> host(static_cast<size_t>(n_steps));
@@ -1082,6 +1312,7 @@ int lbm_step_finish(lbm_ctx* c, void* stream)
   if (!c) { lbm_internal::set_error("lbm_step_finish: null context"); return 1; }
   hipStream_t s = pick_stream(c, stream);
   c->n_prev = c->n_part_interior + c->n_part_boundary;
+  c->n_prev_vecs = 1;
   c->parity ^= 1;
   c->cur ^= 1;                                                              // d2q9-bgk.c:376-378
   c->run_done += 1;
@@ -1089,7 +1320,7 @@ int lbm_step_finish(lbm_ctx* c, void* stream)
     HIP_TRY(hipEventRecord(c->ev_end, s));
     c->ev_launches = c->run_steps * ((c->n_part_interior > 0 ? 1 : 0) + 1);
     c->ev_valid = true;
-    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->sums, c->counter);
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
     HIP_TRY(hipGetLastError());
     c->n_prev = 0;
   }
@@ -1126,7 +1357,8 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
+    if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
+    else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
     else std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");
   }

@@ -21,7 +21,7 @@ a = ap.parse_args()
 nx, ny = (int(v) for v in a.grid.split("x"))
 p = lbm.Params(nx, ny, a.steps, 10, 0.1, 0.005, 1.85)
 obst = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
-KNOBS = ["LBM_TUNE_MAXBLOCKS", "LBM_TUNE_SKEW", "LBM_TUNE_VARIANT", "LBM_TUNE_BLOCK", "LBM_TUNE_ONEALLOC", "LBM_TUNE_GRIDGAP", "LBM_TUNE_NARROW_MAX"]
+KNOBS = ["LBM_TUNE_MAXBLOCKS", "LBM_TUNE_SKEW", "LBM_TUNE_VARIANT", "LBM_TUNE_BLOCK", "LBM_TUNE_ONEALLOC", "LBM_TUNE_GRIDGAP", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM"]
 res = {c: [] for c in a.configs}
 for r in range(a.rounds):
     for cfg in a.configs:
@@ -39,7 +39,7 @@ for r in range(a.rounds):
         sim.run(10)
         sim.run(a.steps)
         ms, n = sim.partition.last_run_kernel_ms()
-        res[cfg].append(ms / n * 1e3)
+        res[cfg].append(ms / a.steps * 1e3)      # per lattice step (a launch may cover several steps)
         sim.close()
 for cfg, v in res.items():
     print(f"{cfg:60s} min {min(v):8.1f}  med {statistics.median(v):8.1f}  max {max(v):8.1f} us/step   " + " ".join(f"{x:.0f}" for x in v), flush=True)

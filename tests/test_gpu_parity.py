@@ -42,12 +42,16 @@ def load_case(lbm, digests, name):
     return p, obst, free
 
 
-@pytest.fixture(params=["vector", "auto"])
+@pytest.fixture(params=["vector", "narrow", "auto"])
 def kernel_form(request, monkeypatch):
-    """"vector": force the 4-cells-per-lane kernel on every size; "auto": the library's choice (one
-    cell per lane up to 64 K cells)."""
+    """Which step kernel lbm_run uses on the small test grids: "vector" = 4 cells per lane on every
+    size; "narrow" = the library's choice among the one-step kernels (one cell per lane up to 64 K
+    cells); "auto" = the library's full choice (up to 8 steps per launch with lbm_tile_kernel on
+    periodic grids whose edges are multiples of 16 and that hold <= 256 K cells)."""
     if request.param == "vector":
         monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
+    if request.param in ("vector", "narrow"):
+        monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
     return request.param
 
 
@@ -304,6 +308,7 @@ def test_lds_staged_kernel_same_results(lbm, oracle, digests, monkeypatch, name)
     """LBM_FLAG_KERNEL_LDS: the LDS-tiled form of the step kernel (aligned loads, x+-1 neighbours and
     the obstacle bitfield through LDS) must give the same bits as the direct-load form."""
     monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
     p, obst, free = load_case(lbm, digests, name)
     steps = min(p.max_iters, 150)
     s = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_KERNEL_LDS)
@@ -359,6 +364,7 @@ def test_row_lengths_not_multiple_of_four(lbm, oracle, nx, ny):
 @pytest.mark.parametrize("name", ["rand_64x48", "walls_40x24", "accelrow_blocked_32x16", "strongaccel_32x16", "synth_512x512_t100"])
 def test_narrow_kernel_on_regular_decks(lbm, oracle, digests, monkeypatch, name):
     monkeypatch.setenv("LBM_TUNE_NARROW_MAX", str(1 << 30))
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
     p, obst, free = load_case(lbm, digests, name)
     steps = min(p.max_iters, 150)
     s = lbm.Simulation(p, obst)
@@ -395,3 +401,21 @@ def test_python_cli_under_torchrun_world_of_one(lbm, digests, tmp_path):
     assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
     av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+
+
+@pytest.mark.parametrize("nx,ny,steps", [(16, 16, 37), (32, 16, 8), (16, 48, 9), (64, 32, 1), (128, 128, 100), (512, 256, 23)])
+@pytest.mark.parametrize("geom", ["168", "164", "88", "84"])
+def test_tile_kernel_shapes_and_step_counts(lbm, oracle, monkeypatch, geom, nx, ny, steps):
+    """lbm_tile_kernel: grids smaller than the 32x32 region (the region then wraps around the domain
+    more than once), step counts that are not multiples of 8, repeated calls."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", str(1 << 30))
+    monkeypatch.setenv("LBM_TUNE_TILE_GEOM", geom)     # T*10 + H: owned tile edge, ghost ring / steps per launch
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.02, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.07, nx * 7 + ny, False)
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"].startswith("lbm_tile_kernel<")
+    av = np.concatenate([s.run(steps), s.run(5), s.run(8)])
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps + 13)
+    assert np.array_equal(bits(s.local_cells()), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    s.close()
