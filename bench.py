@@ -138,6 +138,8 @@ def main() -> None:
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "LBM_FORCE_DEVICE" in os.environ:          # testing aid: several ranks on one device (if the communicator allows it)
+        local_rank = int(os.environ["LBM_FORCE_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

@@ -32,6 +32,8 @@ def main(argv) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "LBM_FORCE_DEVICE" in os.environ:          # testing aid: several ranks on one device (if the communicator allows it)
+        local_rank = int(os.environ["LBM_FORCE_DEVICE"])
     try:
         params = lbm.read_params(argv[1])
         obstacles, _ = lbm.read_obstacles(argv[2], params.nx, params.ny)
@@ -42,10 +44,14 @@ def main(argv) -> int:
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("LBM_DIST_BACKEND", "nccl")     # "gloo": host-staged halos (testing aid)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     try:
         sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1,
-                             exchange=os.environ.get("LBM_EXCHANGE", "rccl"))
+                             exchange=os.environ.get("LBM_EXCHANGE", "rccl" if os.environ.get("LBM_DIST_BACKEND", "nccl") == "nccl" else "torch"))
     except lbm.LbmError as e:
         die(str(e))
     if dist is not None:

@@ -148,10 +148,6 @@ class Partition:
         check(self._lib.lbm_run(self._ctx, n_steps, _capi.as_float_ptr(av)))
         return av[:n_steps]
 
-    def run_untimed_result(self, n_steps: int) -> None:
-        """Same as run() but leaves the per-step sums on the device (no host copy)."""
-        check(self._lib.lbm_run(self._ctx, n_steps, None))
-
     # -- state --
     def get_cells(self) -> np.ndarray:
         cells = np.empty((self.ny_local, self.params.nx, _capi.NSPEEDS), dtype=np.float32)
@@ -259,6 +255,10 @@ class HaloExchange:
         self.size = dist.get_world_size(group)
         self.south = (self.rank - 1) % self.size      # reference `top`    (:245-246)
         self.north = (self.rank + 1) % self.size      # reference `bottom` (:247)
+        # gloo cannot move device memory: device halo buffers are then staged through host copies
+        # (testing aid — lets several ranks share one GPU, which RCCL refuses)
+        self.host_staged = dist.get_backend(group) == "gloo"
+        self._staging = None
 
     def _global(self, group_rank: int) -> int:
         return self._dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
@@ -268,24 +268,37 @@ class HaloExchange:
         receive order [north, south] exactly as the reference's request arrays (`:295-303`), which
         is what keeps the two messages apart when both neighbours are the same rank (size 2)."""
         d = self._dist
+        send_s, send_n = part.halo_send(SOUTH), part.halo_send(NORTH)
+        recv_s, recv_n = part.halo_recv(SOUTH), part.halo_recv(NORTH)
+        self._staging = None
+        if self.host_staged and send_s.is_cuda:
+            self._staging = (recv_s, recv_n, recv_s.cpu(), recv_n.cpu())
+            send_s, send_n = send_s.cpu(), send_n.cpu()          # synchronising device-to-host copies
+            recv_s, recv_n = self._staging[2], self._staging[3]
         ops = [
-            d.P2POp(d.isend, part.halo_send(SOUTH), self._global(self.south), self.group, tag=0),
-            d.P2POp(d.isend, part.halo_send(NORTH), self._global(self.north), self.group, tag=1),
-            d.P2POp(d.irecv, part.halo_recv(NORTH), self._global(self.north), self.group, tag=0),
-            d.P2POp(d.irecv, part.halo_recv(SOUTH), self._global(self.south), self.group, tag=1),
+            d.P2POp(d.isend, send_s, self._global(self.south), self.group, tag=0),
+            d.P2POp(d.isend, send_n, self._global(self.north), self.group, tag=1),
+            d.P2POp(d.irecv, recv_n, self._global(self.north), self.group, tag=0),
+            d.P2POp(d.irecv, recv_s, self._global(self.south), self.group, tag=1),
         ]
         return d.batch_isend_irecv(ops)
 
-    @staticmethod
-    def wait(requests) -> None:
+    def wait(self, requests) -> None:
         """`MPI_Waitall` (`:364`).  On nccl this only makes the current stream wait; the host goes on."""
         for r in requests:
             r.wait()
+        if self._staging is not None:
+            dev_s, dev_n, host_s, host_n = self._staging
+            dev_s.copy_(host_s)
+            dev_n.copy_(host_n)
+            self._staging = None
 
     def allreduce_sum(self, values: np.ndarray, torch_device) -> np.ndarray:
         """The end-of-run `MPI_Reduce(..., MPI_SUM, ...)` (`:396`), here as an all-reduce."""
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(values)).to(torch_device)
+        t = torch.from_numpy(np.ascontiguousarray(values))
+        if not self.host_staged:
+            t = t.to(torch_device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
@@ -435,9 +448,13 @@ class Simulation:
         import torch.distributed as dist
         if self._torch_device is None:
             self._torch_device = torch.device("cuda", self.device)
-        mine = torch.from_numpy(local).to(self._torch_device)
+        if dist.get_backend(self.exchange.group) == "gloo":
+            self._gather_device = torch.device("cpu")
+        else:
+            self._gather_device = self._torch_device
+        mine = torch.from_numpy(local).to(self._gather_device)
         if self.rank == 0:
-            parts = [torch.empty((n, self.params.nx, _capi.NSPEEDS), dtype=torch.float32, device=self._torch_device)
+            parts = [torch.empty((n, self.params.nx, _capi.NSPEEDS), dtype=torch.float32, device=self._gather_device)
                      for n in self.ny_local]
             parts[0] = mine
             for r in range(1, self.size):
