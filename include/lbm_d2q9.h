@@ -48,6 +48,8 @@ typedef struct lbm_ctx lbm_ctx;     /* opaque: device state of one partition */
 #define LBM_FLAG_KERNEL_LDS    4u   /* use the LDS-staged row kernel instead of the direct-load kernel */
 #define LBM_FLAG_GRAPH        16u   /* lbm_run: replay 64-step hipGraphs instead of launching every step (measured: no
                                        gain on MI355X, the small grids are bound by device-side launch latency) */
+#define LBM_FLAG_ONE_STEP     32u   /* row-partitioned run: keep the one-step split-phase calls (lbm_step_*) even when
+                                       the partition is eligible for K-step mode (lbm_macro_*) */
 #define LBM_FLAG_FORCE_HALO    8u   /* treat a whole-grid partition like any other rank: edge rows read the halo
                                        buffers (a 1-rank run that exchanges with itself, d2q9-bgk.c:245-247) */
 
@@ -77,6 +79,15 @@ int lbm_decompose(int ny, int size, int* ny_local, int* displs);
 int lbm_create(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacles_rows,
                int y0, int ny_local, int device, unsigned flags);
 int lbm_destroy(lbm_ctx* ctx);
+
+/* Same, given the GLOBAL obstacle map (ny*nx ints, as rank 0 of the reference holds it before the
+ * Scatterv, d2q9-bgk.c:917-970).  Knowing the rows around the partition lets a row-partitioned
+ * context run in K-step mode: K ghost rows on each side of the owned rows, refreshed by the
+ * neighbours every K steps, all steps done K at a time by lbm_multi_kernel (lbm_macro_* below).
+ * Chosen when nx % 64 == 0, ny_local % 16 == 0, ny_local >= 32 and LBM_FLAG_ONE_STEP is not set;
+ * lbm_macro_steps() tells.  Self-contained domains (ny_local == ny) are unaffected. */
+int lbm_create_global(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacles_all,
+                      int y0, int ny_local, int device, unsigned flags);
 
 /* Replaces the whole timestep loop d2q9-bgk.c:315-394 for a self-contained domain
  * (ny_local == ny): n_steps x { accelerate_flow (:442-478); timestep (:493-704); av_vels[tt]
@@ -120,6 +131,30 @@ int    lbm_step_prepare(lbm_ctx* ctx, int n_steps, void* stream);
 int    lbm_step_interior(lbm_ctx* ctx, void* stream);
 int    lbm_step_boundary(lbm_ctx* ctx, void* stream);
 int    lbm_step_finish(lbm_ctx* ctx, void* stream);
+/* ---- K-step stepping of a row-partitioned run (contexts from lbm_create_global) ------------------
+ *
+ * One macro-step = min(K, steps left) iterations of d2q9-bgk.c:315-378 with ONE halo exchange:
+ *     [caller: for each of the 9 planes, send lbm_macro_send_ptr(dir, plane) to the neighbour in
+ *      direction dir and receive lbm_macro_recv_ptr(dir, plane) from it: lbm_macro_halo_floats()
+ *      floats = K whole rows each; the pointers refer to the CURRENT grid and change every macro-step]
+ *     lbm_macro_interior(ctx, stream)   tiles that need no ghost row, overlaps the exchange
+ *     [exchange complete]
+ *     lbm_macro_edge(ctx, stream)       first and last tile row
+ *     lbm_macro_finish(ctx, stream)     swap grids, advance the step counter by the macro-step's steps
+ * lbm_macro_prepare / lbm_step_collect / lbm_step_sums_device_ptr play the roles they have above.
+ * lbm_macro_steps(): K, or 0 when the context is not in K-step mode (use lbm_step_* then).
+ * lbm_macro_exchange_local(): the exchange between two contexts of one process (device copies):
+ * src's rows travelling in direction dir become dst's ghost rows. */
+int    lbm_macro_steps(const lbm_ctx* ctx);
+size_t lbm_macro_halo_floats(const lbm_ctx* ctx);
+void*  lbm_macro_send_ptr(lbm_ctx* ctx, int dir, int plane);
+void*  lbm_macro_recv_ptr(lbm_ctx* ctx, int dir, int plane);
+int    lbm_macro_prepare(lbm_ctx* ctx, int n_steps, void* stream);
+int    lbm_macro_interior(lbm_ctx* ctx, void* stream);
+int    lbm_macro_edge(lbm_ctx* ctx, void* stream);
+int    lbm_macro_finish(lbm_ctx* ctx, void* stream);
+int    lbm_macro_exchange_local(lbm_ctx* dst, lbm_ctx* src, int dir, void* stream);
+
 /* After the last lbm_step_finish of a run: this partition's per-step tot_u sums (double, device
  * resident until now) for the n_steps steps since lbm_step_prepare.  The caller reduces them over
  * partitions (the reference's MPI_Reduce, d2q9-bgk.c:396) and scales by free_cells_inv. */

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 ABI_VERSION = 1
 NSPEEDS = 9
 
-FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH = 0, 1, 2, 4, 8, 16
+FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP = 0, 1, 2, 4, 8, 16, 32
 
 
 class LbmError(RuntimeError):
@@ -39,6 +39,7 @@ _SIGNATURES = {
     "lbm_read_obstacles": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_decompose": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_create": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "lbm_create_global": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_destroy": (C.c_int, [_ctx]),
     "lbm_run": (C.c_int, [_ctx, C.c_int, _P(C.c_float)]),
     "lbm_get_cells": (C.c_int, [_ctx, _P(C.c_float)]),
@@ -52,6 +53,15 @@ _SIGNATURES = {
     "lbm_step_interior": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_step_boundary": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_step_finish": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_macro_steps": (C.c_int, [_ctx]),
+    "lbm_macro_halo_floats": (C.c_size_t, [_ctx]),
+    "lbm_macro_send_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
+    "lbm_macro_recv_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
+    "lbm_macro_prepare": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "lbm_macro_interior": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_macro_edge": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_macro_finish": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_macro_exchange_local": (C.c_int, [_ctx, _ctx, C.c_int, C.c_void_p]),
     "lbm_step_collect": (C.c_int, [_ctx, C.c_void_p, _P(C.c_double), C.c_int]),
     "lbm_step_sums_device_ptr": (C.c_void_p, [_ctx]),
     "lbm_last_run_kernel_ms": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_int)]),

@@ -631,6 +631,293 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H)) lbm_tile_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K steps per pass over HBM for bandwidth-bound grids: lbm_multi_kernel<K>.
+//
+// The one-step kernel moves 72 B per cell-step and sits at ~90 % of what HBM delivers; the only way
+// further up is to touch memory less often.  Here a 512-lane block owns a 64x16 tile and advances it
+// by up to K steps per launch: sub-step 1 pulls straight from the source grid (as the one-step kernel
+// does) for the tile plus a (K-1)-cell ring and keeps the result in LDS; sub-steps 2..K update that
+// LDS frame in place (neighbours read into registers, barrier, results written back), each on a
+// region one cell smaller; the last sub-step covers exactly the owned tile and writes the
+// destination grid.  The ring is recomputed redundantly by the neighbouring blocks with the same
+// arithmetic, so no block ever waits for another, and the results are bit-identical to K launches of
+// the one-step kernel.  HBM traffic per K steps: (64+2K)(16+2K)/1024 x 36 B read + 36 B written
+// (K = 2: 84 B instead of 144 B; K = 4: 97 B instead of 288 B).
+//
+// Rows outside the partition: `y_periodic` wraps (self-contained domain); otherwise the storage has
+// `ghost` extra rows below and above the owned rows, filled by the neighbours before the launch.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMTX = 64, kMTY = 16, kMLanes = 512, kMaxMultiSteps = 4;
+
+// Sub-step j of k (1-based) works on the owned tile grown by (k-j) rows and 2(k-j) columns on each
+// side: columns grow twice as fast so that every region starts on an even x and a lane can own an
+// x-PAIR of cells (8-byte accesses; the two cells' arithmetic is packed by the compiler into
+// v_pk_*_f32, which halves the instruction count - the one-cell form of this kernel was VALU-bound).
+template <int K>
+struct MultiGeom {
+  static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
+  static constexpr int W = kMTX + 2 * EX, H = kMTY + 2 * EY;        // LDS frame
+  static constexpr int cells = W * H;
+  static constexpr int pairs2 = K >= 2 ? ((kMTX + 4 * (K - 2)) / 2) * (kMTY + 2 * (K - 2)) : 0;   // largest in-LDS region
+  static constexpr int passes = (pairs2 + kMLanes - 1) / kMLanes;
+  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64);
+};
+
+struct MultiArgs {
+  const float* src;
+  float* dst;
+  const uint32_t* mask;        // bit per STORAGE cell (ghost rows included)
+  size_t ps;
+  int nx;
+  int rows_owned;              // owned rows
+  int ghost;                   // storage rows before the first owned row (0 when y_periodic)
+  int y_periodic;
+  int y0_global, ny_global;    // global row of the first owned row; global grid height
+  int tiles_x;
+  int tile_begin, tile_count, tile_begin2, tile_count2;   // tile ranges of this launch (second may be empty)
+  int ntiles_total;            // stride of partials_out
+  int ksteps;                  // 1..K steps in this launch
+  int xcd_remap;               // tile order: contiguous eighth per XCD (needs (tile_count+tile_count2) % 8 == 0)
+  float omega, accel_w1, accel_w2;
+  int accel_row;               // GLOBAL row ny-2
+  int accel_last;
+  double* partials_out;        // [ksteps][ntiles_total]
+  const double* prev_partials; // previous launch: [n_prev_vecs][n_prev]
+  int n_prev, n_prev_vecs;
+  double* sums;
+  int* counter;
+};
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ void bounce_or_relax(const float (&t)[9], const float (&o)[9], bool blocked, float (&out)[9])
+{
+  out[0] = blocked ? t[0] : o[0];                                       // bounce-back d2q9-bgk.c:687-695
+  out[1] = blocked ? t[3] : o[1];
+  out[2] = blocked ? t[4] : o[2];
+  out[3] = blocked ? t[1] : o[3];
+  out[4] = blocked ? t[2] : o[4];
+  out[5] = blocked ? t[7] : o[5];
+  out[6] = blocked ? t[8] : o[6];
+  out[7] = blocked ? t[5] : o[7];
+  out[8] = blocked ? t[6] : o[8];
+}
+
+__device__ __forceinline__ void accelerate_cell(float (&out)[9], float w1, float w2)   // d2q9-bgk.c:457-469
+{
+  if (out[3] - w1 > 0.0f && out[6] - w2 > 0.0f && out[7] - w2 > 0.0f) {
+    out[1] += w1; out[5] += w2; out[8] += w2;
+    out[3] -= w1; out[6] -= w2; out[7] -= w2;
+  }
+}
+
+// Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
+// p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
+__device__ __forceinline__ void finish_pair(const f2 (&p)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
+                                            f2 (&out)[9], double (&term)[2])
+{
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float t[9], o[9], r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = p[k][j];
+    const double tm = relax_cell(t, omega, o);
+    const bool blocked = (mbits >> j) & 1u;
+    bounce_or_relax(t, o, blocked, r);
+    if (accel && !blocked) accelerate_cell(r, w1, w2);
+    term[j] = blocked ? 0.0 : tm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k][j] = r[k];
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
+{
+  using G = MultiGeom<K>;
+  constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
+  double* red = reinterpret_cast<double*>(lds + 9 * kCells);
+  const int tid = threadIdx.x;
+
+  if (blockIdx.x == 0) {
+    // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
+    for (int v = 0; v < a.n_prev_vecs; ++v) {
+      double s = 0.0;
+      for (int i = tid; i < a.n_prev; i += kMLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
+      s = wave_sum(s);
+      __syncthreads();
+      if ((tid & 63) == 0) red[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kWaves; ++w) t += red[w];
+        a.sums[*a.counter + v] = t;
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
+    return;
+  }
+
+  int b = blockIdx.x - 1;
+  if (a.xcd_remap) {
+    // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD one contiguous eighth of
+    // the launch so that tiles which overlap (x and y neighbours) meet in the same L2
+    const int nb = gridDim.x - 1, per = nb >> 3;
+    b = (b & 7) * per + (b >> 3);
+  }
+  const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int x0 = tx * kMTX;
+  const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
+  const size_t ps = a.ps;
+  const int nx = a.nx;
+  const int rows_storage = a.rows_owned + 2 * a.ghost;
+  const int ksteps = a.ksteps;
+  double acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) acc[i] = 0.0;
+
+  // storage row -> does it hold the global accelerate row ny-2 ?
+  auto on_accel_row = [&](int sr) {
+    int g = a.y0_global + sr - a.ghost;
+    if (g < 0) g += a.ny_global; else if (g >= a.ny_global) g -= a.ny_global;
+    return g == a.accel_row;
+  };
+
+  // ---- sub-step 1: pull from the source grid; region = owned tile grown by (ksteps-1) rows / 2(ksteps-1) columns
+  {
+    const int ey = ksteps - 1, ex = 2 * ey;
+    const int wp = (kMTX + 2 * ex) / 2;                                 // pairs per region row
+    const int np = wp * (kMTY + 2 * ey);
+    for (int i = tid; i < np; i += kMLanes) {
+      const int ry = i / wp, rp = i - ry * wp;
+      const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
+      int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;            // periodic (:527-529)
+      int sr = sy0 + fy - EY;
+      int ys = sr - 1, yn = sr + 1;
+      if (a.y_periodic) {                                                                 // periodic (:245-247)
+        if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
+        ys = (sr == 0) ? rows_storage - 1 : sr - 1;
+        yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
+      }
+      const float* here = a.src + static_cast<size_t>(sr) * nx + gx;
+      const float* south = a.src + static_cast<size_t>(ys) * nx + gx;
+      const float* north = a.src + static_cast<size_t>(yn) * nx + gx;
+      f2 p[9];
+      p[0] = *reinterpret_cast<const f2*>(here);                                           // :530
+      p[2] = *reinterpret_cast<const f2*>(south + 2 * ps);                                 // :532
+      p[4] = *reinterpret_cast<const f2*>(north + 4 * ps);                                 // :534
+      p[1] = *reinterpret_cast<const f2u*>(here + ps - 1);                                 // :531
+      p[5] = *reinterpret_cast<const f2u*>(south + 5 * ps - 1);                            // :535
+      p[8] = *reinterpret_cast<const f2u*>(north + 8 * ps - 1);                            // :538
+      p[3] = *reinterpret_cast<const f2u*>(here + 3 * ps + 1);                             // :533
+      p[6] = *reinterpret_cast<const f2u*>(south + 6 * ps + 1);                            // :536
+      p[7] = *reinterpret_cast<const f2u*>(north + 7 * ps + 1);                            // :537
+      if (gx == 0) {                          // x_w wraps to nx-1 (:529)
+        p[1].x = here[ps + nx - 1]; p[5].x = south[5 * ps + nx - 1]; p[8].x = north[8 * ps + nx - 1];
+      }
+      if (gx == nx - 2) {                     // x_e wraps to 0 (:527-528)
+        p[3].y = here[3 * ps + 2 - nx]; p[6].y = south[6 * ps + 2 - nx]; p[7].y = north[7 * ps + 2 - nx];
+      }
+      const int cell = sr * nx + gx;
+      const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+      f2 out[9];
+      double term[2];
+      finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, out, term);
+      const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
+      if (owned) acc[0] += term[0] + term[1];
+      if (ksteps > 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], reinterpret_cast<f2*>(a.dst + k * ps + cell));
+      }
+    }
+  }
+  if constexpr (K >= 2) {
+    __syncthreads();
+    // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller
+#pragma unroll 1
+    for (int j = 2; j <= ksteps; ++j) {
+      const int ey = ksteps - j, ex = 2 * ey;
+      const int wp = (kMTX + 2 * ex) / 2;
+      const int np = wp * (kMTY + 2 * ey);
+      const bool last = j == ksteps;
+      f2 outs[G::passes][9];
+      int slot[G::passes];
+#pragma unroll
+      for (int q = 0; q < G::passes; ++q) {
+        const int i = tid + q * kMLanes;
+        slot[q] = -1;
+        if (i < np) {
+          const int ry = i / wp, rp = i - ry * wp;
+          const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;
+          const int c = fy * W + fx;
+          f2 p[9];
+          p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + c);
+          p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + c - W);
+          p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + c + W);
+          p[1] = f2{lds[1 * kCells + c - 1], lds[1 * kCells + c]};
+          p[5] = f2{lds[5 * kCells + c - W - 1], lds[5 * kCells + c - W]};
+          p[8] = f2{lds[8 * kCells + c + W - 1], lds[8 * kCells + c + W]};
+          p[3] = f2{lds[3 * kCells + c + 1], lds[3 * kCells + c + 2]};
+          p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
+          p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
+          int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;
+          int sr = sy0 + fy - EY;
+          if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
+          const int cell = sr * nx + gx;
+          const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+          double term[2];
+          finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, outs[q], term);
+          const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
+          if (owned) {
+#pragma unroll
+            for (int m = 1; m < K; ++m)
+              if (m == j - 1) acc[m] += term[0] + term[1];
+          }
+          slot[q] = last ? cell : c;
+        }
+      }
+      if (!last) {
+        __syncthreads();                       // every lane has read its neighbours
+#pragma unroll
+        for (int q = 0; q < G::passes; ++q)
+          if (slot[q] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + slot[q]) = outs[q][k];
+          }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int q = 0; q < G::passes; ++q)
+          if (slot[q] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[q][k], reinterpret_cast<f2*>(a.dst + k * ps + slot[q]));
+          }
+      }
+    }
+  }
+
+  // per-step sums over the owned cells of this tile
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const double w = wave_sum(acc[q]);
+    if ((tid & 63) == 0) red[q * kWaves + (tid >> 6)] = w;
+  }
+  __syncthreads();
+  if (tid < ksteps) {
+    double t = 0.0;
+    for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
+    a.partials_out[static_cast<size_t>(tid) * a.ntiles_total + tile] = t;
+  }
+}
+
 // Folds the last step's partials after the loop.
 __global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, int nvecs, double* sums, int* counter)
 {
@@ -767,8 +1054,9 @@ struct lbm_ctx {
   unsigned flags = 0;
   bool self_periodic = true;
   int accel_row = -1;
+  int ghost = 0;             // storage rows below / above the owned rows (K-step kernels of a row-partitioned run)
   bool nt_stores = false;
-  size_t ncells = 0, ps = 0, grid_floats = 0;
+  size_t ncells = 0, ncells_storage = 0, ps = 0, grid_floats = 0;   // owned cells; cells incl. ghost rows; plane stride
   float* grid_alloc[2] = {nullptr, nullptr};
   float* grid[2] = {nullptr, nullptr};       // plane 0 row 0 (after the front guard)
   int cur = 0;
@@ -801,6 +1089,8 @@ struct lbm_ctx {
   int parity = 0;            // partials buffer written by the current step
   int n_prev = 0;            // partial count of the previous step (0 = nothing to fold)
   int n_prev_vecs = 1;       // ... and how many step vectors of that length the previous launch left (tile kernel: up to 8)
+  int multi_K = 0;           // > 0: bandwidth-bound grid advanced K steps per launch by lbm_multi_kernel<K>
+  int multi_tiles_x = 0, multi_tiles = 0;
   bool tile_kernel = false;  // lbm_run advances several steps per launch with lbm_tile_kernel (small grids)
   int tile_T = 16, tile_H = 8;   // its geometry: owned tile edge, ghost ring = max steps per launch
   int n_tiles = 0;
@@ -882,6 +1172,42 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
   }
 }
 
+template <int K>
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a)
+{
+  using G = MultiGeom<K>;
+  lbm_multi_kernel<K><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
+}
+
+// One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
+void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t1, int n1, bool fold, hipStream_t s)
+{
+  MultiArgs a{};
+  a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
+  a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx;
+  a.rows_owned = c->nyl; a.ghost = c->ghost; a.y_periodic = c->self_periodic ? 1 : 0;
+  a.y0_global = c->y0; a.ny_global = c->p.ny;
+  a.tiles_x = c->multi_tiles_x;
+  a.tile_begin = t0; a.tile_count = n0; a.tile_begin2 = t1; a.tile_count2 = n1;
+  a.ntiles_total = c->multi_tiles;
+  a.ksteps = ksteps;
+  a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
+  a.accel_row = c->p.ny - 2; a.accel_last = accel_last ? 1 : 0;
+  a.partials_out = c->partials[c->parity];
+  a.prev_partials = c->partials[c->parity ^ 1];
+  a.n_prev = fold ? c->n_prev : 0; a.n_prev_vecs = (fold && c->n_prev > 0) ? c->n_prev_vecs : 0;
+  a.sums = c->sums; a.counter = c->counter;
+  const int blocks = n0 + n1;
+  // measured on 8192x8192, K=2: 515 us/step with the XCD-contiguous tile order, 549 without
+  a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
+  switch (c->multi_K) {
+    case 1: launch_multi_k<1>(blocks, s, a); break;
+    case 2: launch_multi_k<2>(blocks, s, a); break;
+    case 3: launch_multi_k<3>(blocks, s, a); break;
+    default: launch_multi_k<4>(blocks, s, a); break;
+  }
+}
+
 template <int T, int H>
 void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a)
 {
@@ -902,11 +1228,12 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
     // accelerate_flow of step 0 (d2q9-bgk.c:345-348); later steps get it from the kernel epilogue
     const int nx = c->p.nx;
     hipLaunchKernelGGL(lbm_accelerate_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps,
-                       c->mask, nx, c->accel_row, c->accel_w1, c->accel_w2);
+                       c->mask, nx, c->ghost + c->accel_row, c->accel_w1, c->accel_w2);
     HIP_TRY(hipGetLastError());
   }
   c->ev_valid = false;
   c->ev_launches = 0;
+  c->ev_tile_launches = 0;
   HIP_TRY(hipEventRecord(c->ev_begin, s));
   return 0;
 }
@@ -952,10 +1279,10 @@ int ensure_graph(lbm_ctx* c, hipStream_t s)
 
 }  // namespace
 
-extern "C" {
-
-int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows, int y0,
-               int ny_local, int device, unsigned flags)
+// lbm_create / lbm_create_global.  obstacles_global (ny*nx, may be null) additionally gives the
+// obstacle flags of the rows around the partition, which the K-step kernels need for their ghost rows.
+static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows,
+                       const int* obstacles_global, int y0, int ny_local, int device, unsigned flags)
 {
   if (!out || !p || !obstacles_rows) { lbm_internal::set_error("lbm_create: null argument"); return 1; }
   *out = nullptr;
@@ -984,7 +1311,17 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   c->accel_w1 = p->density * p->accel * 0.111111111111111111111111f;        // d2q9-bgk.c:445
   c->accel_w2 = p->density * p->accel * 0.0277777777777777777777778f;       // d2q9-bgk.c:446
   c->ncells = static_cast<size_t>(p->nx) * ny_local;
-  c->ps = plane_stride_floats(c->ncells);
+  // K-step mode of a row-partitioned run: K ghost rows on each side of the owned rows, refreshed by the
+  // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
+  if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && p->nx % kMTX == 0 && ny_local % kMTY == 0 &&
+      ny_local >= 2 * kMTY) {
+    // measured on a 1-rank ring (us/step; one-step loop 116 / 37): 8192x1024 rows K=2 108, K=3 71, K=4 74;
+    // 1024x128 rows K=2 44, K=3 30, K=4 25 -- the exchange (36 messages) costs ~50 us per macro-step
+    const int k = tune_env("LBM_TUNE_MACRO_K", c->ncells < (1u << 21) ? 4 : 3);
+    if (k > 0) { c->multi_K = std::min(k, kMaxMultiSteps); c->ghost = c->multi_K; }
+  }
+  c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
+  c->ps = plane_stride_floats(c->ncells_storage);
   c->grid_floats = 9 * c->ps + 128;
   // non-temporal output stores once the two grids no longer fit the 256 MiB Infinity Cache
   const size_t state_bytes = 2 * 9 * c->ncells * sizeof(float);
@@ -1029,10 +1366,20 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
     }
   }
   // obstacle bitfield
-  const size_t mwords = (c->ncells + 31) / 32 + 4;
+  const size_t mwords = (c->ncells_storage + 31) / 32 + 4;
   std::vector<uint32_t> bits(mwords, 0u);
-  for (size_t i = 0; i < c->ncells; ++i)
-    if (obstacles_rows[i]) bits[i >> 5] |= 1u << (i & 31);
+  if (c->ghost == 0) {
+    for (size_t i = 0; i < c->ncells; ++i)
+      if (obstacles_rows[i]) bits[i >> 5] |= 1u << (i & 31);
+  } else {
+    for (int r = 0; r < ny_local + 2 * c->ghost; ++r) {          // storage row -> global row, periodic
+      int g = (y0 + r - c->ghost) % p->ny;
+      if (g < 0) g += p->ny;
+      const int* row = obstacles_global + static_cast<size_t>(g) * p->nx;
+      for (int x = 0; x < p->nx; ++x)
+        if (row[x]) { const size_t i = static_cast<size_t>(r) * p->nx + x; bits[i >> 5] |= 1u << (i & 31); }
+    }
+  }
   c->mask_words = static_cast<int>(mwords);
   HIP_TRY_C(hipMalloc(&c->mask, sizeof(uint32_t) * mwords));
   HIP_TRY_C(hipMemcpy(c->mask, bits.data(), sizeof(uint32_t) * mwords, hipMemcpyHostToDevice));
@@ -1067,7 +1414,18 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   c->n_tiles = (p->nx % c->tile_T == 0 && ny_local % c->tile_T == 0) ? (p->nx / c->tile_T) * (ny_local / c->tile_T) : 0;
   c->tile_kernel = self_periodic && c->n_tiles > 0 &&
                    c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 262144));
-  if (c->tile_kernel) {
+  if (c->ghost > 0) {
+    c->tile_kernel = false;
+    c->multi_tiles_x = p->nx / kMTX;
+    c->multi_tiles = c->multi_tiles_x * (ny_local / kMTY);
+    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
+  } else if (!c->tile_kernel && self_periodic && p->nx % kMTX == 0 && ny_local % kMTY == 0) {
+    // K steps per pass over HBM (lbm_multi_kernel): measured on 8192x8192, us/step: K=1 853, K=2 520
+    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 2), 0), kMaxMultiSteps);
+    c->multi_tiles_x = p->nx / kMTX;
+    c->multi_tiles = c->multi_tiles_x * (ny_local / kMTY);
+    if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
+  } else if (c->tile_kernel) {
     c->partials_cap = std::max(c->partials_cap, kMaxTileSteps * c->n_tiles + 1);
     // up to 74 KB of dynamic LDS per block (two 9 x R x R float buffers): above the 64 KB default limit
     {
@@ -1083,14 +1441,29 @@ int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* ob
   // initial state (d2q9-bgk.c:880-902)
   {
     const float w0 = p->density * 4.0f / 9.0f, w1 = p->density / 9.0f, w2 = p->density / 36.0f;
-    const int blocks = static_cast<int>((c->ncells + 255) / 256);
-    hipLaunchKernelGGL(lbm_init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->grid[0], c->ps, c->ncells, w0, w1, w2);
+    const int blocks = static_cast<int>((c->ncells_storage + 255) / 256);
+    hipLaunchKernelGGL(lbm_init_kernel, dim3(blocks), dim3(256), 0, c->stream, c->grid[0], c->ps, c->ncells_storage, w0, w1, w2);
     HIP_TRY_C(hipGetLastError());
   }
   HIP_TRY_C(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_C
   *out = c;
   return 0;
+}
+
+extern "C" {
+
+int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows, int y0,
+               int ny_local, int device, unsigned flags)
+{
+  return create_impl(out, p, free_cells, obstacles_rows, nullptr, y0, ny_local, device, flags);
+}
+
+int lbm_create_global(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_all, int y0,
+                      int ny_local, int device, unsigned flags)
+{
+  if (!obstacles_all || !p || y0 < 0) { lbm_internal::set_error("lbm_create_global: bad argument"); return 1; }
+  return create_impl(out, p, free_cells, obstacles_all + static_cast<size_t>(y0) * p->nx, obstacles_all, y0, ny_local, device, flags);
 }
 
 int lbm_destroy(lbm_ctx* c)
@@ -1122,7 +1495,19 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   hipStream_t s = c->stream;
   if (begin_run(c, n_steps, s)) return 1;
   int tile_launches = 0;
-  for (int t = 0; c->tile_kernel && t < n_steps;) {
+  const bool multi = c->multi_K > 0 && c->self_periodic;
+  for (int t = 0; multi && t < n_steps;) {
+    // up to multi_K steps per pass over HBM (lbm_multi_kernel)
+    const int k = std::min(c->multi_K, n_steps - t);
+    launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, c->multi_tiles, 0, 0, /*fold=*/true, s);
+    c->n_prev = c->multi_tiles; c->n_prev_vecs = k;
+    c->parity ^= 1;
+    c->cur ^= 1;
+    t += k;
+    ++tile_launches;
+    if (t >= n_steps) c->ev_tile_launches = tile_launches;
+  }
+  for (int t = 0; !multi && c->tile_kernel && t < n_steps;) {
     // up to tile_H steps per launch (lbm_tile_kernel); every launch of such a run has this form
     const int k = std::min(c->tile_H, n_steps - t);
     TileArgs a{};
@@ -1147,7 +1532,7 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     t += k;
     if (t >= n_steps) c->ev_tile_launches = tile_launches;
   }
-  for (int t = 0; !c->tile_kernel && t < n_steps;) {
+  for (int t = 0; !multi && !c->tile_kernel && t < n_steps;) {
     // launch-bound grids: replay a captured block of kGraphSteps steps while at least one more
     // step follows it (the last step of a run is launched directly: it must not accelerate)
     if (c->use_graph && c->n_prev > 0 && n_steps - t > kGraphSteps) {
@@ -1161,7 +1546,7 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev_end, s));
-  c->ev_launches = c->tile_kernel ? c->ev_tile_launches : n_steps;
+  c->ev_launches = (multi || c->tile_kernel) ? c->ev_tile_launches : n_steps;
   c->ev_valid = true;
   hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
   HIP_TRY(hipGetLastError());
@@ -1188,7 +1573,8 @@ int lbm_get_cells(lbm_ctx* c, float* cells_aos)
   const size_t n = c->ncells * 9;
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * n));
   const int blocks = static_cast<int>((n + 255) / 256);
-  hipLaunchKernelGGL(lbm_soa_to_aos_kernel, dim3(blocks), dim3(256), 0, c->stream, c->grid[c->cur], tmp, c->ps, c->ncells);
+  hipLaunchKernelGGL(lbm_soa_to_aos_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                     c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, tmp, c->ps, c->ncells);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(cells_aos, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1207,7 +1593,8 @@ int lbm_set_cells(lbm_ctx* c, const float* cells_aos)
   hipError_t e = hipMemcpyAsync(tmp, cells_aos, sizeof(float) * n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     const int blocks = static_cast<int>((n + 255) / 256);
-    hipLaunchKernelGGL(lbm_aos_to_soa_kernel, dim3(blocks), dim3(256), 0, c->stream, tmp, c->grid[c->cur], c->ps, c->ncells);
+    hipLaunchKernelGGL(lbm_aos_to_soa_kernel, dim3(blocks), dim3(256), 0, c->stream, tmp,
+                       c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps, c->ncells);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1223,7 +1610,10 @@ int lbm_av_velocity_sum(lbm_ctx* c, double* tot_u)
   const int blocks = static_cast<int>(std::min<size_t>((c->ncells + kBlock - 1) / kBlock, 1024));
   double* part = nullptr;
   HIP_TRY(hipMalloc(&part, sizeof(double) * blocks));
-  hipLaunchKernelGGL(lbm_av_velocity_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, c->grid[c->cur], c->ps, c->mask, c->ncells, part);
+  // owned rows only; in K-step mode they start ghost rows in (ghost*nx is a multiple of 64 cells there)
+  hipLaunchKernelGGL(lbm_av_velocity_kernel, dim3(blocks), dim3(kBlock), 0, c->stream,
+                     c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps,
+                     c->mask + static_cast<size_t>(c->ghost) * c->p.nx / 32, c->ncells, part);
   std::vector<double> host(blocks);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, sizeof(double) * blocks, hipMemcpyDeviceToHost, c->stream);
@@ -1254,6 +1644,7 @@ int lbm_bind_halo_buffers(lbm_ctx* c, void* send_south, void* send_north, void* 
 int lbm_step_prepare(lbm_ctx* c, int n_steps, void* stream)
 {
   if (!c || n_steps < 0) { lbm_internal::set_error("lbm_step_prepare: bad argument"); return 1; }
+  if (c->ghost > 0) { lbm_internal::set_error("lbm_step_prepare: the context runs in K-step mode; use the lbm_macro_* calls"); return 1; }
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = pick_stream(c, stream);
   if (begin_run(c, n_steps, s)) return 1;
@@ -1327,6 +1718,99 @@ int lbm_step_finish(lbm_ctx* c, void* stream)
   return 0;
 }
 
+// ---- K-step ("macro-step") stepping of a row-partitioned run ------------------------------------
+
+int lbm_macro_steps(const lbm_ctx* c) { return (c && c->ghost > 0) ? c->multi_K : 0; }
+
+size_t lbm_macro_halo_floats(const lbm_ctx* c) { return (c && c->ghost > 0) ? static_cast<size_t>(c->ghost) * c->p.nx : 0; }
+
+void* lbm_macro_send_ptr(lbm_ctx* c, int dir, int plane)
+{
+  if (!c || c->ghost == 0 || plane < 0 || plane >= 9 || (dir != 0 && dir != 1)) return nullptr;
+  // first K owned rows go south, last K owned rows go north
+  const size_t row = dir == 0 ? static_cast<size_t>(c->ghost) : static_cast<size_t>(c->nyl);
+  return c->grid[c->cur] + plane * c->ps + row * c->p.nx;
+}
+
+void* lbm_macro_recv_ptr(lbm_ctx* c, int dir, int plane)
+{
+  if (!c || c->ghost == 0 || plane < 0 || plane >= 9 || (dir != 0 && dir != 1)) return nullptr;
+  // ghost rows below the first owned row come from the south, those above the last one from the north
+  const size_t row = dir == 0 ? 0 : static_cast<size_t>(c->ghost + c->nyl);
+  return c->grid[c->cur] + plane * c->ps + row * c->p.nx;
+}
+
+int lbm_macro_prepare(lbm_ctx* c, int n_steps, void* stream)
+{
+  if (!c || n_steps < 0 || c->ghost == 0) { lbm_internal::set_error("lbm_macro_prepare: not a K-step context"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  return begin_run(c, n_steps, pick_stream(c, stream));
+}
+
+static int macro_k(const lbm_ctx* c) { return std::min(c->multi_K, c->run_steps - c->run_done); }
+
+int lbm_macro_interior(lbm_ctx* c, void* stream)
+{
+  if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_interior: not a K-step context"); return 1; }
+  if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_interior: no steps left; call lbm_macro_prepare"); return 1; }
+  const int k = macro_k(c), nty = c->nyl / kMTY;
+  if (nty >= 3) {   // tile rows whose K-ring stays inside the owned rows
+    launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * (nty - 2), 0, 0, /*fold=*/true,
+                 pick_stream(c, stream));
+    HIP_TRY(hipGetLastError());
+    c->n_prev = 0;   // folded by this launch's block 0
+  }
+  return 0;
+}
+
+int lbm_macro_edge(lbm_ctx* c, void* stream)
+{
+  if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_edge: not a K-step context"); return 1; }
+  if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_edge: no steps left; call lbm_macro_prepare"); return 1; }
+  const int k = macro_k(c), nty = c->nyl / kMTY;
+  launch_multi(c, k, c->run_done + k < c->run_steps, 0, c->multi_tiles_x, (nty - 1) * c->multi_tiles_x, c->multi_tiles_x,
+               /*fold=*/c->n_prev > 0, pick_stream(c, stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int lbm_macro_finish(lbm_ctx* c, void* stream)
+{
+  if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_finish: not a K-step context"); return 1; }
+  hipStream_t s = pick_stream(c, stream);
+  const int k = macro_k(c);
+  c->n_prev = c->multi_tiles;
+  c->n_prev_vecs = k;
+  c->parity ^= 1;
+  c->cur ^= 1;
+  c->run_done += k;
+  c->ev_tile_launches += 2;
+  if (c->run_done == c->run_steps) {
+    HIP_TRY(hipEventRecord(c->ev_end, s));
+    c->ev_launches = c->ev_tile_launches;
+    c->ev_valid = true;
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
+    HIP_TRY(hipGetLastError());
+    c->n_prev = 0;
+    c->n_prev_vecs = 1;
+  }
+  return 0;
+}
+
+int lbm_macro_exchange_local(lbm_ctx* dst, lbm_ctx* src, int dir, void* stream)
+{
+  if (!dst || !src || dst->ghost == 0 || src->ghost != dst->ghost || src->p.nx != dst->p.nx || (dir != 0 && dir != 1)) {
+    lbm_internal::set_error("lbm_macro_exchange_local: incompatible contexts");
+    return 1;
+  }
+  // src's rows travelling in direction `dir` land in dst's ghost rows on the opposite side
+  hipStream_t s = pick_stream(dst, stream);
+  const size_t bytes = sizeof(float) * lbm_macro_halo_floats(src);
+  for (int k = 0; k < 9; ++k)
+    HIP_TRY(hipMemcpyAsync(lbm_macro_recv_ptr(dst, dir ^ 1, k), lbm_macro_send_ptr(src, dir, k), bytes, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
 int lbm_step_collect(lbm_ctx* c, void* stream, double* tot_u_per_step, int n_steps)
 {
   if (!c || !tot_u_per_step || n_steps > c->run_done) { lbm_internal::set_error("lbm_step_collect: bad argument"); return 1; }
@@ -1357,7 +1841,8 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
+    if (c->multi_K > 0 && c->self_periodic) std::snprintf(kernel_name, len, "lbm_multi_kernel<%d>", c->multi_K);
+    else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
     else std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");

@@ -133,12 +133,57 @@ int lbm_comm_destroy(lbm_comm* c)
   return 0;
 }
 
+// K-step mode (contexts from lbm_create_global, lbm_macro_steps() = K > 0): one exchange of K whole rows
+// of each of the 9 planes per K steps, same three-queue schedule; messages go straight from the
+// sender's edge rows into the receiver's ghost rows (no staging buffers).
+static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
+{
+  lbm_ctx* ctx = c->ctx;
+  const int K = lbm_macro_steps(ctx);
+  const size_t n = lbm_macro_halo_floats(ctx);
+  const bool three_queues = c->three_queues;
+  hipStream_t edge_stream = three_queues ? c->edge : c->compute;
+  LBM_TRY(lbm_macro_prepare(ctx, n_steps, c->compute));   // step-0 accelerate_flow
+  HIP_TRY(hipEventRecord(c->edge_done, c->compute));
+  HIP_TRY(hipEventRecord(c->interior_done, c->compute));
+  for (int done = 0; done < n_steps; done += K) {
+    HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));   // the rows to send were written by the last edge launch
+    NCCL_TRY(ncclGroupStart());
+    for (int k = 0; k < LBM_NSPEEDS; ++k) {                  // order as in the one-step loop: sends [S, N], receives [N, S]
+      NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
+      NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
+      NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
+      NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipEventRecord(c->halo, c->side));
+    if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+    LBM_TRY(lbm_macro_interior(ctx, c->compute));
+    HIP_TRY(hipStreamWaitEvent(edge_stream, c->halo, 0));
+    if (three_queues) HIP_TRY(hipStreamWaitEvent(c->edge, c->interior_done, 0));
+    LBM_TRY(lbm_macro_edge(ctx, edge_stream));
+    HIP_TRY(hipEventRecord(c->edge_done, edge_stream));
+    if (three_queues) {
+      HIP_TRY(hipEventRecord(c->interior_done, c->compute));
+      if (done + K >= n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+    }
+    LBM_TRY(lbm_macro_finish(ctx, c->compute));
+  }
+  double* sums = static_cast<double*>(lbm_step_sums_device_ptr(ctx));
+  if (c->nranks > 1) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));
+  LBM_TRY(lbm_step_collect(ctx, nullptr, tot_u_per_step, n_steps));
+  HIP_TRY(hipStreamSynchronize(c->side));
+  HIP_TRY(hipStreamSynchronize(c->edge));
+  return 0;
+}
+
 int lbm_comm_run(lbm_comm* c, int n_steps, double* tot_u_per_step)
 {
   if (!c || n_steps < 0 || (n_steps > 0 && !tot_u_per_step)) { lbm_internal::set_error("lbm_comm_run: bad argument"); return 1; }
   if (n_steps == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   lbm_ctx* ctx = c->ctx;
+  if (lbm_macro_steps(ctx) > 0) return run_macro(c, n_steps, tot_u_per_step);
   const size_t n = lbm_halo_floats(ctx);
   float* send_s = static_cast<float*>(lbm_halo_send_ptr(ctx, 0));
   float* send_n = static_cast<float*>(lbm_halo_send_ptr(ctx, 1));

@@ -110,7 +110,9 @@ class Partition:
     """Device state of rows [y0, y0+ny_local) — one `lbm_ctx` (include/lbm_d2q9.h)."""
 
     def __init__(self, params: Params, free_cells: int, obstacles_rows: np.ndarray, y0: int = 0,
-                 device: int = 0, flags: int = 0):
+                 device: int = 0, flags: int = 0, obstacles_global: Optional[np.ndarray] = None):
+        """obstacles_global: the whole (ny, nx) map; when given (`lbm_create_global`) an eligible
+        row partition runs in K-step mode (`macro_steps` > 0) and obstacles_rows is ignored."""
         self._lib = _capi.load_library()
         obst = np.ascontiguousarray(obstacles_rows, dtype=np.int32)
         if obst.ndim != 2 or obst.shape[1] != params.nx:
@@ -119,9 +121,37 @@ class Partition:
         self.free_cells_inv = np.float32(1.0) / np.float32(free_cells)          # d2q9-bgk.c:950
         self._ctx = C.c_void_p()
         cp = _cparams(params)
-        check(self._lib.lbm_create(C.byref(self._ctx), C.byref(cp), free_cells, _capi.as_int_ptr(obst), y0,
-                                   self.ny_local, device, flags))
+        if obstacles_global is not None:
+            glob = np.ascontiguousarray(obstacles_global, dtype=np.int32)
+            if glob.shape != (params.ny, params.nx):
+                raise ValueError("obstacles_global must be (ny, nx)")
+            check(self._lib.lbm_create_global(C.byref(self._ctx), C.byref(cp), free_cells, _capi.as_int_ptr(glob), y0,
+                                              self.ny_local, device, flags))
+        else:
+            check(self._lib.lbm_create(C.byref(self._ctx), C.byref(cp), free_cells, _capi.as_int_ptr(obst), y0,
+                                       self.ny_local, device, flags))
         self._halo_tensors = None
+
+    @property
+    def macro_steps(self) -> int:
+        """K if the partition runs in K-step mode (lbm_macro_*), else 0."""
+        return int(self._lib.lbm_macro_steps(self._ctx))
+
+    def macro_prepare(self, n_steps: int, stream=None) -> None:
+        check(self._lib.lbm_macro_prepare(self._ctx, n_steps, self._stream_ptr(stream)))
+
+    def macro_interior(self, stream=None) -> None:
+        check(self._lib.lbm_macro_interior(self._ctx, self._stream_ptr(stream)))
+
+    def macro_edge(self, stream=None) -> None:
+        check(self._lib.lbm_macro_edge(self._ctx, self._stream_ptr(stream)))
+
+    def macro_finish(self, stream=None) -> None:
+        check(self._lib.lbm_macro_finish(self._ctx, self._stream_ptr(stream)))
+
+    def macro_receive_from(self, src: "Partition", direction: int, stream=None) -> None:
+        """In-process exchange: src's rows travelling in `direction` become this partition's ghost rows."""
+        check(self._lib.lbm_macro_exchange_local(self._ctx, src._ctx, direction, self._stream_ptr(stream)))
 
     # -- lifetime --
     def close(self) -> None:
@@ -391,7 +421,11 @@ class Simulation:
         self.ny_local, self.displs = decompose(params.ny, self.size)
         y0, nyl = self.displs[self.rank], self.ny_local[self.rank]
         self.y0, self.nyl = y0, nyl
-        self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device, flags)
+        # the native RCCL loop runs eligible partitions in K-step mode (needs the whole obstacle map for
+        # the ghost rows); the torch loop drives the one-step split-phase calls
+        one_step = _capi.FLAG_ONE_STEP if exchange == "torch" else 0
+        self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device, flags | one_step,
+                                   obstacles_global=obstacles)
         self._torch_device = None
         self._stream = None
         self._ring: Optional[RcclRing] = None

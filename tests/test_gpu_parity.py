@@ -52,6 +52,8 @@ def kernel_form(request, monkeypatch):
         monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
     if request.param in ("vector", "narrow"):
         monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+        monkeypatch.setenv("LBM_TUNE_MULTI_K", "0")
+        monkeypatch.setenv("LBM_TUNE_MACRO_K", "0")
     return request.param
 
 
@@ -309,6 +311,7 @@ def test_lds_staged_kernel_same_results(lbm, oracle, digests, monkeypatch, name)
     the obstacle bitfield through LDS) must give the same bits as the direct-load form."""
     monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
     monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", "0")
     p, obst, free = load_case(lbm, digests, name)
     steps = min(p.max_iters, 150)
     s = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_KERNEL_LDS)
@@ -324,6 +327,8 @@ def test_lds_staged_kernel_same_results(lbm, oracle, digests, monkeypatch, name)
 @pytest.mark.parametrize("nx,ny", [(4, 3), (12, 7), (36, 5), (1028, 6), (2048, 3)])
 def test_lds_staged_kernel_odd_shapes(lbm, oracle, monkeypatch, nx, ny):
     monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", "0")
     p = lbm.Params(nx, ny, 30, 4, 0.1, 0.01, 1.4)
     obst = lbm.synthetic_obstacles(nx, ny, 0.1, nx * 31 + ny, False)
     if obst.all():
@@ -337,6 +342,7 @@ def test_lds_staged_kernel_odd_shapes(lbm, oracle, monkeypatch, nx, ny):
 
 def test_lds_staged_kernel_in_a_ring(lbm, oracle, digests, monkeypatch):
     monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "0")
     p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
     sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO | lbm._capi.FLAG_KERNEL_LDS, exchange="rccl")
     sim.run(40)
@@ -365,6 +371,8 @@ def test_row_lengths_not_multiple_of_four(lbm, oracle, nx, ny):
 def test_narrow_kernel_on_regular_decks(lbm, oracle, digests, monkeypatch, name):
     monkeypatch.setenv("LBM_TUNE_NARROW_MAX", str(1 << 30))
     monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", "0")
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "0")
     p, obst, free = load_case(lbm, digests, name)
     steps = min(p.max_iters, 150)
     s = lbm.Simulation(p, obst)
@@ -440,3 +448,80 @@ def test_several_ranks_share_the_gpu_over_gloo(lbm, digests, tmp_path, ranks, na
     assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
     av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 100), ("synth_512x512_t100", 37), ("1024x1024_t200", 200),
+                                        ("128x128", 41), ("rand_64x48", 103)])
+def test_k_steps_per_pass_kernel(lbm, oracle, digests, monkeypatch, name, steps, K):
+    """lbm_multi_kernel<K>: a 64x16 tile advanced by up to K steps per launch (ring recomputed
+    redundantly, intermediate states in LDS, in place); step counts that are not multiples of K end
+    with a shorter launch.  Must be bit-identical to the one-step path."""
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", str(K))
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    p, obst, free = load_case(lbm, digests, name)
+    assert p.nx % 64 == 0 and p.ny % 16 == 0
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"] == f"lbm_multi_kernel<{K}>"
+    av = np.concatenate([s.run(steps), s.run(3)])
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps + 3, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 61), ("128x128", 50), ("1024x1024_t200", 30)])
+def test_k_step_mode_on_a_ring_of_one(lbm, oracle, digests, monkeypatch, name, steps, K):
+    """K-step mode of a row-partitioned run (lbm_create_global -> K ghost rows, lbm_macro_*): the native
+    RCCL loop on a 1-rank ring, the rank's ghost rows filled from its own edge rows over RCCL."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    assert sim.partition.macro_steps == K
+    av = np.concatenate([sim.run(steps), sim.run(5)])
+    cells = sim.local_cells()
+    sim.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps + 5, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("name,size,K", [("synth_512x512_t100", 2, 2), ("synth_512x512_t100", 4, 3), ("synth_512x512_t100", 8, 4),
+                                         ("synth_512x512_t100", 16, 2), ("1024x1024_t200", 8, 4), ("128x128", 4, 1)])
+def test_k_step_mode_with_several_partitions(lbm, oracle, digests, monkeypatch, name, size, K):
+    """Several K-step partitions of one grid on one GPU, ghost rows exchanged by device copies
+    (lbm_macro_exchange_local) in the order of the native loop: must equal the single-partition run."""
+    import torch
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    p, obst, free = load_case(lbm, digests, name)
+    steps = min(p.max_iters, 45)
+    ny_local, displs = lbm.decompose(p.ny, size)
+    parts = [lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r], obstacles_global=obst) for r in range(size)]
+    assert all(part.macro_steps == K for part in parts)
+    tstream = torch.cuda.Stream(torch.device("cuda", 0))
+    st = tstream.cuda_stream
+    with torch.cuda.stream(tstream):
+        for part in parts:
+            part.macro_prepare(steps, st)
+        done = 0
+        while done < steps:
+            for r, part in enumerate(parts):
+                part.macro_receive_from(parts[(r - 1) % size], lbm.NORTH, st)    # southern neighbour's top rows
+                part.macro_receive_from(parts[(r + 1) % size], lbm.SOUTH, st)    # northern neighbour's bottom rows
+            for part in parts:
+                part.macro_interior(st)
+                part.macro_edge(st)
+            for part in parts:
+                part.macro_finish(st)
+            done += K
+        sums = sum(part.step_collect(steps, st) for part in parts)
+    tstream.synchronize()
+    cells = np.concatenate([part.get_cells() for part in parts], axis=0)
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    av = sums * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+    for part in parts:
+        part.close()
