@@ -11,6 +11,11 @@
 //                                                  written already accelerated for the next step
 //   av_vels[tt-1]          d2q9-bgk.c:367          block 0 folds the previous launch's partials
 //
+// Kernels in this file (all produce the same bits; lbm_run / the partitioned loop pick by grid size):
+//   lbm_step_kernel / _narrow / _lds   one step per launch (4 cells, 1 cell per lane; LDS-staged variant)
+//   lbm_multi_kernel<K>                K steps per pass over HBM, 64x16 tiles, intermediate states in LDS
+//   lbm_tile_kernel<T,H>               up to H steps per launch for the launch-latency-bound small grids
+//
 // Layout in HBM: struct-of-arrays, 9 planes of ny_local*nx floats (plane stride padded, see
 // plane_stride_floats()), two grids (source / destination, swapped per step like :376-378), the
 // obstacle map as a bitfield (1 bit per cell).  Every population value is consumed by exactly one
@@ -793,6 +798,7 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
     const int ey = ksteps - 1, ex = 2 * ey;
     const int wp = (kMTX + 2 * ex) / 2;                                 // pairs per region row
     const int np = wp * (kMTY + 2 * ey);
+#pragma unroll 1
     for (int i = tid; i < np; i += kMLanes) {
       const int ry = i / wp, rp = i - ry * wp;
       const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
