@@ -116,7 +116,17 @@ __device__ __forceinline__ void fold_previous(const StepArgs& a, double* red);
 
 // One cell: moments, equilibrium, relaxation in the reference's operation order (d2q9-bgk.c:546-666).
 // t[] = streamed-in populations, o[] = relaxed populations; returns sqrt(m^2)/rho in double (:667).
+__device__ __forceinline__ void relax_cell_core(const float (&t)[9], float omega, float (&o)[9], float& msq_out, float& rinv_out);
+
 __device__ __forceinline__ double relax_cell(const float (&t)[9], float omega, float (&o)[9])
+{
+  float msq, rinv;
+  relax_cell_core(t, omega, o, msq, rinv);
+  return sqrt(static_cast<double>(msq)) * static_cast<double>(rinv);   // :667
+}
+
+// The same without the sum|u| term: msq = m^2 (un-normalised momentum squared), rinv = 1/rho.
+__device__ __forceinline__ void relax_cell_core(const float (&t)[9], float omega, float (&o)[9], float& msq_out, float& rinv_out)
 {
   const float csq_inv = 3.0f;                                   // :497
   const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;   // :499-501
@@ -143,7 +153,8 @@ __device__ __forceinline__ double relax_cell(const float (&t)[9], float omega, f
     const float q = wk * (rho + a + h * (b - msq));             // :639-646
     o[k] = t[k] + omega * (q - t[k]);                           // :659-666
   }
-  return sqrt(static_cast<double>(msq)) * static_cast<double>(rinv);   // :667
+  msq_out = msq;
+  rinv_out = rinv;
 }
 
 // Row bases of the three source rows of destination row y, per population (d2q9-bgk.c:511-512,
@@ -720,25 +731,34 @@ __device__ __forceinline__ void accelerate_cell(float (&out)[9], float w1, float
 
 // Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
 // p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
-__device__ __forceinline__ void finish_pair(const f2 (&p)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
-                                            f2 (&out)[9], double (&term)[2])
+// Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
+// double-precision sqrt is a tenth of the cell's instructions).
+__device__ __forceinline__ double finish_pair(const f2 (&p)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
+                                              bool want_term, f2 (&out)[9])
 {
+  float msq[2], rinv[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     float t[9], o[9], r[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) t[k] = p[k][j];
-    const double tm = relax_cell(t, omega, o);
+    relax_cell_core(t, omega, o, msq[j], rinv[j]);
     const bool blocked = (mbits >> j) & 1u;
     bounce_or_relax(t, o, blocked, r);
     if (accel && !blocked) accelerate_cell(r, w1, w2);
-    term[j] = blocked ? 0.0 : tm;
 #pragma unroll
     for (int k = 0; k < 9; ++k) out[k][j] = r[k];
   }
+  double term = 0.0;
+  if (want_term) {
+    const double t0 = sqrt(static_cast<double>(msq[0])) * static_cast<double>(rinv[0]);   // :667
+    const double t1 = sqrt(static_cast<double>(msq[1])) * static_cast<double>(rinv[1]);
+    term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
+  }
+  return term;
 }
 
-template <int K>
+template <int K, bool FULL>   // FULL: this launch does exactly K steps (all region sizes are compile-time constants)
 __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K>;
@@ -781,7 +801,7 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
   const size_t ps = a.ps;
   const int nx = a.nx;
   const int rows_storage = a.rows_owned + 2 * a.ghost;
-  const int ksteps = a.ksteps;
+  const int ksteps = FULL ? K : a.ksteps;
   double acc[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) acc[i] = 0.0;
@@ -832,10 +852,8 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
       const int cell = sr * nx + gx;
       const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
       f2 out[9];
-      double term[2];
-      finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, out, term);
       const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
-      if (owned) acc[0] += term[0] + term[1];
+      acc[0] += finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
@@ -879,14 +897,12 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
           if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
           const int cell = sr * nx + gx;
           const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
-          double term[2];
-          finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, outs[q], term);
           const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
-          if (owned) {
+          const double term = finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
+                                          owned, outs[q]);
 #pragma unroll
-            for (int m = 1; m < K; ++m)
-              if (m == j - 1) acc[m] += term[0] + term[1];
-          }
+          for (int m = 1; m < K; ++m)
+            if (m == j - 1) acc[m] += term;
           slot[q] = last ? cell : c;
         }
       }
@@ -1182,7 +1198,8 @@ template <int K>
 void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a)
 {
   using G = MultiGeom<K>;
-  lbm_multi_kernel<K><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
+  if (a.ksteps == K) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
+  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
 }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
