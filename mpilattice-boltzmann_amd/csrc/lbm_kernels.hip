@@ -1436,15 +1436,17 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   }
   c->n_tiles = (p->nx % c->tile_T == 0 && ny_local % c->tile_T == 0) ? (p->nx / c->tile_T) * (ny_local / c->tile_T) : 0;
   c->tile_kernel = self_periodic && c->n_tiles > 0 &&
-                   c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 262144));
+                   c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 65536));   // 512x512: lbm_multi_kernel<3> 3.5 us/step vs 5.2 here
   if (c->ghost > 0) {
     c->tile_kernel = false;
     c->multi_tiles_x = p->nx / kMTX;
     c->multi_tiles = c->multi_tiles_x * (ny_local / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
   } else if (!c->tile_kernel && self_periodic && p->nx % kMTX == 0 && ny_local % kMTY == 0) {
-    // K steps per pass over HBM (lbm_multi_kernel): measured on 8192x8192, us/step: K=1 853, K=2 520
-    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 2), 0), kMaxMultiSteps);
+    // K steps per pass over HBM (lbm_multi_kernel), measured us/step for K = 2 / 3 / 4 (one-step kernel):
+    //   8192x8192 515 / 532 / 556 (853-917)   2048x2048 34.0 / 35.0 / 35.7 (59)
+    //   1024x1024 11.4 / 10.0 / 10.2 (13.5)   512x512 3.9 / 3.5 / 3.6 (6.3; lbm_tile_kernel 5.2)
+    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells <= (1u << 21) ? 3 : 2), 0), kMaxMultiSteps);
     c->multi_tiles_x = p->nx / kMTX;
     c->multi_tiles = c->multi_tiles_x * (ny_local / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
