@@ -1866,7 +1866,7 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    if (c->multi_K > 0 && c->self_periodic) std::snprintf(kernel_name, len, "lbm_multi_kernel<%d>", c->multi_K);
+    if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, "lbm_multi_kernel<%d>", c->multi_K);
     else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
