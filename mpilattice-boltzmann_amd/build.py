@@ -5,6 +5,7 @@ outputs (lib/, bin/) are git-ignored but travel to the GPU box with the tree.  g
 """
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -40,6 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     headers = [os.path.join(ROOT, "include", "lbm_d2q9.h"), os.path.join(CSRC, "lbm_internal.h"), os.path.abspath(__file__)]
+    headers += sorted(glob.glob(os.path.join(CSRC, "kernels", "*.h")))       # device code, included by lbm_kernels.hip
     lib_src = [os.path.join(CSRC, "lbm_kernels.hip"), os.path.join(CSRC, "lbm_host.cpp")]
     if force or _stale(LIB, lib_src + headers):
         cmd = [hipcc, "--offload-arch=gfx950", *COMMON, "-fPIC", "-shared", *lib_src, "-o", LIB]

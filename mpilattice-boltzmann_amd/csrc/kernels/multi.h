@@ -1,0 +1,277 @@
+// multi.h — lbm_multi_kernel<K>: K steps per pass over HBM for the bandwidth-bound grids and for K-step row partitions
+// Part of the single translation unit lbm_kernels.hip (device code of liblbm_d2q9.so, gfx950 only).
+#pragma once
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// K steps per pass over HBM for bandwidth-bound grids: lbm_multi_kernel<K>.
+//
+// The one-step kernel moves 72 B per cell-step and sits at ~90 % of what HBM delivers; the only way
+// further up is to touch memory less often.  Here a 512-lane block owns a 64x16 tile and advances it
+// by up to K steps per launch: sub-step 1 pulls straight from the source grid (as the one-step kernel
+// does) for the tile plus a (K-1)-cell ring and keeps the result in LDS; sub-steps 2..K update that
+// LDS frame in place (neighbours read into registers, barrier, results written back), each on a
+// region one cell smaller; the last sub-step covers exactly the owned tile and writes the
+// destination grid.  The ring is recomputed redundantly by the neighbouring blocks with the same
+// arithmetic, so no block ever waits for another, and the results are bit-identical to K launches of
+// the one-step kernel.  HBM traffic per K steps: (64+2K)(16+2K)/1024 x 36 B read + 36 B written
+// (K = 2: 84 B instead of 144 B; K = 4: 97 B instead of 288 B).
+//
+// Rows outside the partition: `y_periodic` wraps (self-contained domain); otherwise the storage has
+// `ghost` extra rows below and above the owned rows, filled by the neighbours before the launch.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMTX = 64, kMTY = 16, kMLanes = 512, kMaxMultiSteps = 4;
+
+// Sub-step j of k (1-based) works on the owned tile grown by (k-j) rows and 2(k-j) columns on each
+// side: columns grow twice as fast so that every region starts on an even x and a lane can own an
+// x-PAIR of cells (8-byte accesses; the two cells' arithmetic is packed by the compiler into
+// v_pk_*_f32, which halves the instruction count - the one-cell form of this kernel was VALU-bound).
+template <int K>
+struct MultiGeom {
+  static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
+  static constexpr int W = kMTX + 2 * EX, H = kMTY + 2 * EY;        // LDS frame
+  static constexpr int cells = W * H;
+  static constexpr int pairs2 = K >= 2 ? ((kMTX + 4 * (K - 2)) / 2) * (kMTY + 2 * (K - 2)) : 0;   // largest in-LDS region
+  static constexpr int passes = (pairs2 + kMLanes - 1) / kMLanes;
+  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64);
+};
+
+struct MultiArgs {
+  const float* src;
+  float* dst;
+  const uint32_t* mask;        // bit per STORAGE cell (ghost rows included)
+  size_t ps;
+  int nx;
+  int rows_owned;              // owned rows
+  int ghost;                   // storage rows before the first owned row (0 when y_periodic)
+  int y_periodic;
+  int y0_global, ny_global;    // global row of the first owned row; global grid height
+  int tiles_x;
+  int tile_begin, tile_count, tile_begin2, tile_count2;   // tile ranges of this launch (second may be empty)
+  int ntiles_total;            // stride of partials_out
+  int ksteps;                  // 1..K steps in this launch
+  int xcd_remap;               // tile order: contiguous eighth per XCD (needs (tile_count+tile_count2) % 8 == 0)
+  float omega, accel_w1, accel_w2;
+  int accel_row;               // GLOBAL row ny-2
+  int accel_last;
+  double* partials_out;        // [ksteps][ntiles_total]
+  const double* prev_partials; // previous launch: [n_prev_vecs][n_prev]
+  int n_prev, n_prev_vecs;
+  double* sums;
+  int* counter;
+};
+
+// Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
+// p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
+// Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
+// double-precision sqrt is a tenth of the cell's instructions).
+__device__ __forceinline__ double finish_pair(const f2 (&p)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
+                                              bool want_term, f2 (&out)[9])
+{
+  float msq[2], rinv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float t[9], o[9], r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = p[k][j];
+    relax_cell_core(t, omega, o, msq[j], rinv[j]);
+    const bool blocked = (mbits >> j) & 1u;
+    bounce_or_relax(t, o, blocked, r);
+    if (accel && !blocked) accelerate_cell(r, w1, w2);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[k][j] = r[k];
+  }
+  double term = 0.0;
+  if (want_term) {
+    const double t0 = sqrt(static_cast<double>(msq[0])) * static_cast<double>(rinv[0]);   // :667
+    const double t1 = sqrt(static_cast<double>(msq[1])) * static_cast<double>(rinv[1]);
+    term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
+  }
+  return term;
+}
+
+template <int K, bool FULL>   // FULL: this launch does exactly K steps (all region sizes are compile-time constants)
+__global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
+{
+  using G = MultiGeom<K>;
+  constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
+  double* red = reinterpret_cast<double*>(lds + 9 * kCells);
+  const int tid = threadIdx.x;
+
+  if (blockIdx.x == 0) {
+    // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
+    for (int v = 0; v < a.n_prev_vecs; ++v) {
+      double s = 0.0;
+      for (int i = tid; i < a.n_prev; i += kMLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
+      s = wave_sum(s);
+      __syncthreads();
+      if ((tid & 63) == 0) red[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kWaves; ++w) t += red[w];
+        a.sums[*a.counter + v] = t;
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
+    return;
+  }
+
+  int b = blockIdx.x - 1;
+  if (a.xcd_remap) {
+    // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD one contiguous eighth of
+    // the launch so that tiles which overlap (x and y neighbours) meet in the same L2
+    const int nb = gridDim.x - 1, per = nb >> 3;
+    b = (b & 7) * per + (b >> 3);
+  }
+  const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int x0 = tx * kMTX;
+  const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
+  const size_t ps = a.ps;
+  const int nx = a.nx;
+  const int rows_storage = a.rows_owned + 2 * a.ghost;
+  const int ksteps = FULL ? K : a.ksteps;
+  double acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) acc[i] = 0.0;
+
+  // storage row -> does it hold the global accelerate row ny-2 ?
+  auto on_accel_row = [&](int sr) {
+    int g = a.y0_global + sr - a.ghost;
+    if (g < 0) g += a.ny_global; else if (g >= a.ny_global) g -= a.ny_global;
+    return g == a.accel_row;
+  };
+
+  // ---- sub-step 1: pull from the source grid; region = owned tile grown by (ksteps-1) rows / 2(ksteps-1) columns
+  {
+    const int ey = ksteps - 1, ex = 2 * ey;
+    const int wp = (kMTX + 2 * ex) / 2;                                 // pairs per region row
+    const int np = wp * (kMTY + 2 * ey);
+#pragma unroll 1
+    for (int i = tid; i < np; i += kMLanes) {
+      const int ry = i / wp, rp = i - ry * wp;
+      const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
+      int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;            // periodic (:527-529)
+      int sr = sy0 + fy - EY;
+      int ys = sr - 1, yn = sr + 1;
+      if (a.y_periodic) {                                                                 // periodic (:245-247)
+        if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
+        ys = (sr == 0) ? rows_storage - 1 : sr - 1;
+        yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
+      }
+      const float* here = a.src + static_cast<size_t>(sr) * nx + gx;
+      const float* south = a.src + static_cast<size_t>(ys) * nx + gx;
+      const float* north = a.src + static_cast<size_t>(yn) * nx + gx;
+      f2 p[9];
+      p[0] = *reinterpret_cast<const f2*>(here);                                           // :530
+      p[2] = *reinterpret_cast<const f2*>(south + 2 * ps);                                 // :532
+      p[4] = *reinterpret_cast<const f2*>(north + 4 * ps);                                 // :534
+      p[1] = *reinterpret_cast<const f2u*>(here + ps - 1);                                 // :531
+      p[5] = *reinterpret_cast<const f2u*>(south + 5 * ps - 1);                            // :535
+      p[8] = *reinterpret_cast<const f2u*>(north + 8 * ps - 1);                            // :538
+      p[3] = *reinterpret_cast<const f2u*>(here + 3 * ps + 1);                             // :533
+      p[6] = *reinterpret_cast<const f2u*>(south + 6 * ps + 1);                            // :536
+      p[7] = *reinterpret_cast<const f2u*>(north + 7 * ps + 1);                            // :537
+      if (gx == 0) {                          // x_w wraps to nx-1 (:529)
+        p[1].x = here[ps + nx - 1]; p[5].x = south[5 * ps + nx - 1]; p[8].x = north[8 * ps + nx - 1];
+      }
+      if (gx == nx - 2) {                     // x_e wraps to 0 (:527-528)
+        p[3].y = here[3 * ps + 2 - nx]; p[6].y = south[6 * ps + 2 - nx]; p[7].y = north[7 * ps + 2 - nx];
+      }
+      const int cell = sr * nx + gx;
+      const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+      f2 out[9];
+      const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
+      acc[0] += finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
+      if (ksteps > 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], reinterpret_cast<f2*>(a.dst + k * ps + cell));
+      }
+    }
+  }
+  if constexpr (K >= 2) {
+    __syncthreads();
+    // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller
+#pragma unroll 1
+    for (int j = 2; j <= ksteps; ++j) {
+      const int ey = ksteps - j, ex = 2 * ey;
+      const int wp = (kMTX + 2 * ex) / 2;
+      const int np = wp * (kMTY + 2 * ey);
+      const bool last = j == ksteps;
+      f2 outs[G::passes][9];
+      int slot[G::passes];
+#pragma unroll
+      for (int q = 0; q < G::passes; ++q) {
+        const int i = tid + q * kMLanes;
+        slot[q] = -1;
+        if (i < np) {
+          const int ry = i / wp, rp = i - ry * wp;
+          const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;
+          const int c = fy * W + fx;
+          f2 p[9];
+          p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + c);
+          p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + c - W);
+          p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + c + W);
+          p[1] = f2{lds[1 * kCells + c - 1], lds[1 * kCells + c]};
+          p[5] = f2{lds[5 * kCells + c - W - 1], lds[5 * kCells + c - W]};
+          p[8] = f2{lds[8 * kCells + c + W - 1], lds[8 * kCells + c + W]};
+          p[3] = f2{lds[3 * kCells + c + 1], lds[3 * kCells + c + 2]};
+          p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
+          p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
+          int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;
+          int sr = sy0 + fy - EY;
+          if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
+          const int cell = sr * nx + gx;
+          const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+          const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
+          const double term = finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
+                                          owned, outs[q]);
+#pragma unroll
+          for (int m = 1; m < K; ++m)
+            if (m == j - 1) acc[m] += term;
+          slot[q] = last ? cell : c;
+        }
+      }
+      if (!last) {
+        __syncthreads();                       // every lane has read its neighbours
+#pragma unroll
+        for (int q = 0; q < G::passes; ++q)
+          if (slot[q] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + slot[q]) = outs[q][k];
+          }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int q = 0; q < G::passes; ++q)
+          if (slot[q] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[q][k], reinterpret_cast<f2*>(a.dst + k * ps + slot[q]));
+          }
+      }
+    }
+  }
+
+  // per-step sums over the owned cells of this tile
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const double w = wave_sum(acc[q]);
+    if ((tid & 63) == 0) red[q * kWaves + (tid >> 6)] = w;
+  }
+  __syncthreads();
+  if (tid < ksteps) {
+    double t = 0.0;
+    for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
+    a.partials_out[static_cast<size_t>(tid) * a.ntiles_total + tile] = t;
+  }
+}
+
+}  // namespace

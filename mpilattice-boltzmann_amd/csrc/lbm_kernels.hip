@@ -42,997 +42,13 @@
 
 #include "lbm_d2q9.h"
 #include "lbm_internal.h"
+#include "kernels/common.h"
+#include "kernels/step.h"
+#include "kernels/tile.h"
+#include "kernels/multi.h"
+#include "kernels/aux.h"
 
 namespace {
-
-constexpr int kBlock = 256;          // 4 wavefronts
-constexpr int kCellsPerLane = 4;     // one 16-byte access per population per lane
-constexpr int kHaloGuard = 4;        // floats of guard on each side of a halo-buffer row
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
-
-struct StepArgs {
-  const float* src;            // source grid, plane 0 row 0
-  float* dst;                  // destination grid
-  const uint32_t* mask;        // obstacle bitfield, bit c of the partition-local cell index
-  int mask_words;              // words allocated for it
-  size_t ps;                   // plane stride in floats
-  int nx, nyl;                 // row length, rows owned by this partition
-  int quad_begin, quad_end;    // 4-cell groups [begin,end) of the partition handled by this launch
-  int quad_begin2, quad_end2;  // optional second range (boundary launch: last row), empty if begin2>=end2
-  int iters;                   // 1024-cell chunks per block
-  // sources outside the partition (row-partitioned runs); nullptr = periodic wrap inside the plane
-  const float* south_halo;     // populations 2,5,6 of the row below row 0   [3][nxp], data at +kHaloGuard
-  const float* north_halo;     // populations 4,7,8 of the row above row nyl-1
-  float* send_south;           // row 0's populations 4,7,8 for the southern neighbour (next step)
-  float* send_north;           // row nyl-1's populations 2,5,6 for the northern neighbour
-  int nxp;                     // halo-buffer row pitch = nx + 2*kHaloGuard
-  float omega;
-  float accel_w1, accel_w2;    // d2q9-bgk.c:445-446
-  int accel_row;               // local row that is global row ny-2, or -1: epilogue accelerate for the NEXT step
-  double* partials_out;        // this launch's per-block sums
-  const double* prev_partials; // previous step's per-block sums, folded by block 0 of this launch
-  int n_prev;
-  double* sums;                // per-step totals of this run
-  int* counter;                // index of the next entry of sums
-};
-
-__device__ __forceinline__ f4 load4(const float* p) { return *reinterpret_cast<const f4*>(p); }
-__device__ __forceinline__ f4 load4u(const float* p) { return *reinterpret_cast<const f4u*>(p); }
-
-template <bool NT>
-__device__ __forceinline__ void store4(float* p, f4 v)
-{
-  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
-  else *reinterpret_cast<f4*>(p) = v;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// Deterministic block sum (fixed tree): every thread gets the total.
-__device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 doubles */)
-{
-  v = wave_sum(v);
-  const int wave = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds[wave] = v;
-  __syncthreads();
-  double t = lds[0];
-#pragma unroll
-  for (int w = 1; w < kBlock / 64; ++w) t += lds[w];
-  return t;
-}
-
-// Block 0 of every step launch does no lattice work: it folds the PREVIOUS
-// step's per-block sums into sums[counter++] (d2q9-bgk.c:367) while the other blocks stream, so the
-// fold's latency (a dependent load + two barriers) is off the critical path of the tiny grids.
-__device__ __forceinline__ void fold_previous(const StepArgs& a, double* red);
-
-// One cell: moments, equilibrium, relaxation in the reference's operation order (d2q9-bgk.c:546-666).
-// t[] = streamed-in populations, o[] = relaxed populations; returns sqrt(m^2)/rho in double (:667).
-__device__ __forceinline__ void relax_cell_core(const float (&t)[9], float omega, float (&o)[9], float& msq_out, float& rinv_out);
-
-__device__ __forceinline__ double relax_cell(const float (&t)[9], float omega, float (&o)[9])
-{
-  float msq, rinv;
-  relax_cell_core(t, omega, o, msq, rinv);
-  return sqrt(static_cast<double>(msq)) * static_cast<double>(rinv);   // :667
-}
-
-// The same without the sum|u| term: msq = m^2 (un-normalised momentum squared), rinv = 1/rho.
-__device__ __forceinline__ void relax_cell_core(const float (&t)[9], float omega, float (&o)[9], float& msq_out, float& rinv_out)
-{
-  const float csq_inv = 3.0f;                                   // :497
-  const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;   // :499-501
-  float rho = t[0];                                             // :546-554
-  rho += t[1]; rho += t[2]; rho += t[3]; rho += t[4];
-  rho += t[5]; rho += t[6]; rho += t[7]; rho += t[8];
-  const float rinv = 1.0f / rho;                                // :561
-  float mx = t[1] + t[5];                                       // :570-574
-  mx += t[8]; mx -= t[3]; mx -= t[6]; mx -= t[7];
-  float my = t[2] + t[5];                                       // :576-580
-  my += t[6]; my -= t[4]; my -= t[7]; my -= t[8];
-  const float msq = mx * mx + my * my;                          // :589
-  float e[9];
-  e[1] = mx;       e[2] = my;        e[3] = -mx;       e[4] = -my;        // :596-599
-  e[5] = mx + my;  e[6] = -mx + my;  e[7] = -mx - my;  e[8] = mx - my;    // :600-603
-  const float h = 0.5f * rinv * csq_inv;                        // "0.5f*densinv*ic_sq" of :638-646
-  const float q0 = w0 * (rho - h * msq);                        // :638
-  o[0] = t[0] + omega * (q0 - t[0]);                            // :658
-#pragma unroll
-  for (int k = 1; k < 9; ++k) {
-    const float a = e[k] * csq_inv;                             // :610-617
-    const float b = a * e[k];                                   // :624-631
-    const float wk = (k < 5) ? w1 : w2;
-    const float q = wk * (rho + a + h * (b - msq));             // :639-646
-    o[k] = t[k] + omega * (q - t[k]);                           // :659-666
-  }
-  msq_out = msq;
-  rinv_out = rinv;
-}
-
-// Row bases of the three source rows of destination row y, per population (d2q9-bgk.c:511-512,
-// 526-538): here -> 0,1,3 (+k*ps); south row -> 2,5,6; north row -> 4,7,8.  Rows outside the
-// partition come from the halo messages (row-partitioned runs) or wrap periodically.
-struct RowPtrs {
-  const float *here, *s2, *s5, *s6, *n4, *n7, *n8;
-};
-
-__device__ __forceinline__ RowPtrs source_rows(const StepArgs& a, int y)
-{
-  RowPtrs r;
-  const size_t ps = a.ps;
-  const int nx = a.nx;
-  r.here = a.src + static_cast<size_t>(y) * nx;
-  if (y > 0 || a.south_halo == nullptr) {
-    const int ys = (y > 0) ? y - 1 : a.nyl - 1;                        // periodic wrap (:245-247 with one rank)
-    const float* q = a.src + static_cast<size_t>(ys) * nx;
-    r.s2 = q + 2 * ps; r.s5 = q + 5 * ps; r.s6 = q + 6 * ps;
-  } else {
-    const float* q = a.south_halo + kHaloGuard;
-    r.s2 = q; r.s5 = q + a.nxp; r.s6 = q + 2 * a.nxp;
-  }
-  if (y < a.nyl - 1 || a.north_halo == nullptr) {
-    const int yn = (y < a.nyl - 1) ? y + 1 : 0;
-    const float* q = a.src + static_cast<size_t>(yn) * nx;
-    r.n4 = q + 4 * ps; r.n7 = q + 7 * ps; r.n8 = q + 8 * ps;
-  } else {
-    const float* q = a.north_halo + kHaloGuard;
-    r.n4 = q; r.n7 = q + a.nxp; r.n8 = q + 2 * a.nxp;
-  }
-  return r;
-}
-
-// Everything after the pull for the 4 cells at (y, x0..x0+3), partition-local cell index c:
-// relaxation / bounce-back select, next step's accelerate_flow on row ny-2, stores, outgoing halo
-// rows.  p[k] = streamed-in population k of the four cells.  Returns their sum|u| contribution.
-template <bool NT>
-__device__ __forceinline__ double finish_quad(const StepArgs& a, int c, int y, int x0, const f4 (&p)[9], uint32_t mbits)
-{
-  const size_t ps = a.ps;
-  f4 out[9];
-  double acc = 0.0;
-#pragma unroll
-  for (int j = 0; j < kCellsPerLane; ++j) {
-    float t[9], o[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = p[k][j];
-    const double term = relax_cell(t, a.omega, o);
-    const bool blocked = (mbits >> j) & 1u;
-    // bounce-back (d2q9-bgk.c:687-695): out[opposite(k)] = t[k]
-    out[0][j] = blocked ? t[0] : o[0];
-    out[1][j] = blocked ? t[3] : o[1];
-    out[2][j] = blocked ? t[4] : o[2];
-    out[3][j] = blocked ? t[1] : o[3];
-    out[4][j] = blocked ? t[2] : o[4];
-    out[5][j] = blocked ? t[7] : o[5];
-    out[6][j] = blocked ? t[8] : o[6];
-    out[7][j] = blocked ? t[5] : o[7];
-    out[8][j] = blocked ? t[6] : o[8];
-    acc += blocked ? 0.0 : term;
-  }
-
-  // accelerate_flow for the NEXT step, applied to the freshly written row ny-2 (d2q9-bgk.c:457-469)
-  if (y == a.accel_row) {
-#pragma unroll
-    for (int j = 0; j < kCellsPerLane; ++j) {
-      const bool blocked = (mbits >> j) & 1u;
-      if (!blocked && out[3][j] - a.accel_w1 > 0.0f && out[6][j] - a.accel_w2 > 0.0f &&
-          out[7][j] - a.accel_w2 > 0.0f) {
-        out[1][j] += a.accel_w1; out[5][j] += a.accel_w2; out[8][j] += a.accel_w2;
-        out[3][j] -= a.accel_w1; out[6][j] -= a.accel_w2; out[7][j] -= a.accel_w2;
-      }
-    }
-  }
-
-  float* d = a.dst + c;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) store4<NT>(d + k * ps, out[k]);
-
-  // next step's outgoing halo rows (row-partitioned runs only)
-  if (a.send_south != nullptr && y == 0) {
-    float* s = a.send_south + kHaloGuard + x0;
-    store4<false>(s, out[4]); store4<false>(s + a.nxp, out[7]); store4<false>(s + 2 * a.nxp, out[8]);
-  }
-  if (a.send_north != nullptr && y == a.nyl - 1) {
-    float* s = a.send_north + kHaloGuard + x0;
-    store4<false>(s, out[2]); store4<false>(s + a.nxp, out[5]); store4<false>(s + 2 * a.nxp, out[6]);
-  }
-  return acc;
-}
-
-// Direct-load form: processes the 4 cells starting at partition-local cell index 4*quad
-// (nx % 4 == 0, so the four share a row).
-template <bool NT>
-__device__ __forceinline__ double step_quad(const StepArgs& a, int quad)
-{
-  const int c = quad * kCellsPerLane;
-  const int y = c / a.nx;
-  const int x0 = c - y * a.nx;
-  const size_t ps = a.ps;
-  const int nx = a.nx;
-  const RowPtrs r = source_rows(a, y);
-
-  // pull (d2q9-bgk.c:530-538): aligned for x, dword-shifted for x-1 / x+1
-  f4 p[9];
-  p[0] = load4(r.here + x0);
-  p[2] = load4(r.s2 + x0);
-  p[4] = load4(r.n4 + x0);
-  p[1] = load4u(r.here + ps + x0 - 1);
-  p[5] = load4u(r.s5 + x0 - 1);
-  p[8] = load4u(r.n8 + x0 - 1);
-  p[3] = load4u(r.here + 3 * ps + x0 + 1);
-  p[6] = load4u(r.s6 + x0 + 1);
-  p[7] = load4u(r.n7 + x0 + 1);
-  const uint32_t mword = a.mask[c >> 5];
-  if (x0 == 0) {                       // x_w wraps to nx-1 (:529)
-    p[1].x = r.here[ps + nx - 1];
-    p[5].x = r.s5[nx - 1];
-    p[8].x = r.n8[nx - 1];
-  }
-  if (x0 == nx - kCellsPerLane) {      // x_e wraps to 0 (:527-528)
-    p[3].w = r.here[3 * ps];
-    p[6].w = r.s6[0];
-    p[7].w = r.n7[0];
-  }
-  const uint32_t mbits = (mword >> (c & 31)) & 0xFu;
-  return finish_quad<NT>(a, c, y, x0, p, mbits);
-}
-
-// One-cell-per-lane form: used for grids so small that a step is bound by the latency of one lane's
-// dependent instruction chain rather than by bandwidth (4x more lanes, each with a quarter of the
-// chain), and for row lengths that are not a multiple of 4.  `cell` = partition-local cell index.
-template <bool NT>
-__device__ __forceinline__ double step_cell(const StepArgs& a, int cell)
-{
-  const int y = cell / a.nx;
-  const int x = cell - y * a.nx;
-  const size_t ps = a.ps;
-  const int nx = a.nx;
-  const RowPtrs r = source_rows(a, y);
-  const int xe = (x + 1 >= nx) ? x + 1 - nx : x + 1;                   // :527-528
-  const int xw = (x == 0) ? nx - 1 : x - 1;                             // :529
-  float t[9], o[9];
-  t[0] = r.here[x];            t[1] = r.here[ps + xw];      t[2] = r.s2[x];      // :530-532
-  t[3] = r.here[3 * ps + xe];  t[4] = r.n4[x];              t[5] = r.s5[xw];     // :533-535
-  t[6] = r.s6[xe];             t[7] = r.n7[xe];             t[8] = r.n8[xw];     // :536-538
-  const bool blocked = (a.mask[cell >> 5] >> (cell & 31)) & 1u;
-  const double term = relax_cell(t, a.omega, o);
-  float out[9];
-  out[0] = blocked ? t[0] : o[0];                                       // bounce-back :687-695
-  out[1] = blocked ? t[3] : o[1];
-  out[2] = blocked ? t[4] : o[2];
-  out[3] = blocked ? t[1] : o[3];
-  out[4] = blocked ? t[2] : o[4];
-  out[5] = blocked ? t[7] : o[5];
-  out[6] = blocked ? t[8] : o[6];
-  out[7] = blocked ? t[5] : o[7];
-  out[8] = blocked ? t[6] : o[8];
-  if (y == a.accel_row && !blocked && out[3] - a.accel_w1 > 0.0f && out[6] - a.accel_w2 > 0.0f &&
-      out[7] - a.accel_w2 > 0.0f) {                                     // next step's accelerate_flow :457-469
-    out[1] += a.accel_w1; out[5] += a.accel_w2; out[8] += a.accel_w2;
-    out[3] -= a.accel_w1; out[6] -= a.accel_w2; out[7] -= a.accel_w2;
-  }
-  float* d = a.dst + cell;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    if (NT) __builtin_nontemporal_store(out[k], d + k * ps);
-    else d[k * ps] = out[k];
-  }
-  if (a.send_south != nullptr && y == 0) {
-    float* s = a.send_south + kHaloGuard + x;
-    s[0] = out[4]; s[a.nxp] = out[7]; s[2 * a.nxp] = out[8];
-  }
-  if (a.send_north != nullptr && y == a.nyl - 1) {
-    float* s = a.send_north + kHaloGuard + x;
-    s[0] = out[2]; s[a.nxp] = out[5]; s[2 * a.nxp] = out[6];
-  }
-  return blocked ? 0.0 : term;
-}
-
-// LDS-staged form (LBM_FLAG_KERNEL_LDS), the tiling BASELINE.json's north_star sentence describes:
-// every global load is 16-byte aligned; the x-1 / x+1 values a lane needs from its neighbours'
-// vectors travel through an LDS tile row with one halo column per side (filled from global memory
-// by the first / last lane of the block), and the chunk's 1024 obstacle bits sit in LDS as a
-// bitfield.  Same arithmetic, same results; kept as a measured alternative.
-struct LdsTile {
-  float w[3][kBlock + 2];      // [k][1+lane] = .w of populations 1,5,8 of that lane: the x-1 source of lane+1; [0] = halo
-  float e[3][kBlock + 2];      // [k][1+lane] = .x of populations 3,6,7: the x+1 source of lane-1; [kBlock+1] = halo
-  uint32_t mask[kBlock / 8 + 1];   // the (up to) 33 words holding the chunk's 1024 obstacle bits
-};
-
-template <bool NT>
-__device__ __forceinline__ double step_quad_lds(const StepArgs& a, int quad, bool active, int chunk_first_cell, LdsTile& tile)
-{
-  const int tid = threadIdx.x;
-  const int c = quad * kCellsPerLane;
-  const int y = active ? c / a.nx : 0;
-  const int x0 = c - y * a.nx;
-  const size_t ps = a.ps;
-  const int nx = a.nx;
-  const int word0 = chunk_first_cell >> 5;
-  f4 p[9];
-  float hw[3] = {0.f, 0.f, 0.f}, he[3] = {0.f, 0.f, 0.f};
-  const bool row_start = active && x0 == 0;                       // x_w wraps to nx-1 (:529)
-  const bool row_end = active && x0 == nx - kCellsPerLane;        // x_e wraps to 0   (:527-528)
-  if (tid <= kBlock / 8 && word0 + tid < a.mask_words) tile.mask[tid] = a.mask[word0 + tid];
-  if (active) {
-    const RowPtrs r = source_rows(a, y);
-    p[0] = load4(r.here + x0);
-    p[1] = load4(r.here + ps + x0);
-    p[2] = load4(r.s2 + x0);
-    p[3] = load4(r.here + 3 * ps + x0);
-    p[4] = load4(r.n4 + x0);
-    p[5] = load4(r.s5 + x0);
-    p[6] = load4(r.s6 + x0);
-    p[7] = load4(r.n7 + x0);
-    p[8] = load4(r.n8 + x0);
-    tile.w[0][tid + 1] = p[1].w; tile.w[1][tid + 1] = p[5].w; tile.w[2][tid + 1] = p[8].w;
-    tile.e[0][tid + 1] = p[3].x; tile.e[1][tid + 1] = p[6].x; tile.e[2][tid + 1] = p[7].x;
-    // halo columns of the tile row (only the block's first / last lane have no neighbour lane) and
-    // the periodic wrap for lanes sitting on a row edge inside the block
-    if (tid == 0 || row_start) {
-      const int xw = row_start ? nx - 1 : x0 - 1;
-      hw[0] = r.here[ps + xw]; hw[1] = r.s5[xw]; hw[2] = r.n8[xw];
-      if (tid == 0) { tile.w[0][0] = hw[0]; tile.w[1][0] = hw[1]; tile.w[2][0] = hw[2]; }
-    }
-    if (tid == kBlock - 1 || row_end) {
-      const int xe = row_end ? 0 : x0 + kCellsPerLane;
-      he[0] = r.here[3 * ps + xe]; he[1] = r.s6[xe]; he[2] = r.n7[xe];
-      if (tid == kBlock - 1) { tile.e[0][kBlock + 1] = he[0]; tile.e[1][kBlock + 1] = he[1]; tile.e[2][kBlock + 1] = he[2]; }
-    }
-  }
-  __syncthreads();
-  double acc = 0.0;
-  if (active) {
-    const float w1 = row_start ? hw[0] : tile.w[0][tid], w5 = row_start ? hw[1] : tile.w[1][tid],
-                w8 = row_start ? hw[2] : tile.w[2][tid];
-    const float e3 = row_end ? he[0] : tile.e[0][tid + 2], e6 = row_end ? he[1] : tile.e[1][tid + 2],
-                e7 = row_end ? he[2] : tile.e[2][tid + 2];
-    const f4 c1 = p[1], c5 = p[5], c8 = p[8], c3 = p[3], c6 = p[6], c7 = p[7];
-    p[1] = f4{w1, c1.x, c1.y, c1.z};
-    p[5] = f4{w5, c5.x, c5.y, c5.z};
-    p[8] = f4{w8, c8.x, c8.y, c8.z};
-    p[3] = f4{c3.y, c3.z, c3.w, e3};
-    p[6] = f4{c6.y, c6.z, c6.w, e6};
-    p[7] = f4{c7.y, c7.z, c7.w, e7};
-    const uint32_t mbits = (tile.mask[(c >> 5) - word0] >> (c & 31)) & 0xFu;
-    acc = finish_quad<NT>(a, c, y, x0, p, mbits);
-  }
-  __syncthreads();   // the tile is rewritten by the next chunk
-  return acc;
-}
-
-// Same grid / chunk mapping as lbm_step_kernel, single contiguous quad range only (the two-row
-// boundary launch of a row-partitioned run always uses the direct form).
-template <bool NT>
-__global__ void __launch_bounds__(kBlock) lbm_step_kernel_lds(const StepArgs a)
-{
-  __shared__ double red[kBlock / 64];
-  __shared__ LdsTile tile;
-  if (blockIdx.x == 0) { fold_previous(a, red); return; }
-  const int wblock = blockIdx.x - 1;   // work block index
-  double acc = 0.0;
-  const int n1 = a.quad_end - a.quad_begin;
-  for (int i = 0; i < a.iters; ++i) {
-    const int r0 = (wblock * a.iters + i) * kBlock;          // block-uniform: every lane reaches the barriers
-    if (r0 >= n1) break;
-    const int r = r0 + threadIdx.x;
-    acc += step_quad_lds<NT>(a, a.quad_begin + r, r < n1, (a.quad_begin + r0) * kCellsPerLane, tile);
-  }
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
-}
-
-// The fused streaming-pull step.  Grid: ceil(#quads / (256*iters)) work blocks of 256 lanes (block b
-// owns `iters` consecutive 1024-cell chunks) after one fold block (block 0, dispatched first).
-template <bool NT>
-__global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
-{
-  __shared__ double red[kBlock / 64];
-  if (blockIdx.x == 0) { fold_previous(a, red); return; }
-  const int wblock = blockIdx.x - 1;   // work block index
-  double acc = 0.0;
-  const int n1 = a.quad_end - a.quad_begin;
-  const int n2 = a.quad_end2 > a.quad_begin2 ? a.quad_end2 - a.quad_begin2 : 0;
-  const int base = wblock * a.iters * kBlock + threadIdx.x;
-  for (int i = 0; i < a.iters; ++i) {
-    const int r = base + i * kBlock;
-    if (r < n1 + n2) acc += step_quad<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
-  }
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
-}
-
-// One cell per lane; the unit ranges of StepArgs are cell ranges here.
-template <bool NT>
-__global__ void __launch_bounds__(kBlock) lbm_step_kernel_narrow(const StepArgs a)
-{
-  __shared__ double red[kBlock / 64];
-  if (blockIdx.x == 0) { fold_previous(a, red); return; }
-  const int wblock = blockIdx.x - 1;   // work block index
-  double acc = 0.0;
-  const int n1 = a.quad_end - a.quad_begin;
-  const int n2 = a.quad_end2 > a.quad_begin2 ? a.quad_end2 - a.quad_begin2 : 0;
-  const int base = wblock * a.iters * kBlock + threadIdx.x;
-  for (int i = 0; i < a.iters; ++i) {
-    const int r = base + i * kBlock;
-    if (r < n1 + n2) acc += step_cell<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
-  }
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
-}
-
-__device__ __forceinline__ void fold_previous(const StepArgs& a, double* red)
-{
-  if (a.n_prev <= 0) return;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s += a.prev_partials[i];
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) {
-    const int t = *a.counter;
-    a.sums[t] = s;
-    *a.counter = t + 1;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Temporally blocked form for launch-latency-bound grids (the three small shipped decks).
-//
-// A step of a <= 256 K-cell grid takes less time to compute than a kernel boundary costs, so one
-// launch here advances the lattice by up to H steps (e.g. T = 16, H = 8: a 1024-lane block loads a 32x32
-// region (a 16x16 owned tile + an 8-cell ghost ring, periodic in x and y) into LDS, every lane keeps
-// ONE region cell for the whole launch, and sub-step s recomputes the region shrunk by s cells from
-// the LDS copy of sub-step s-1 (double-buffered, one barrier per sub-step).  Ghost cells are computed
-// redundantly by neighbouring blocks with the same arithmetic, so no block ever waits for another.
-// Per-step sum|u| is taken over owned cells only; accelerate_flow is applied to row ny-2 (ghost
-// copies too) between sub-steps exactly as between launches of the one-step kernels.  Results are
-// bit-identical to the one-step kernels (same relax_cell, same order of steps).
-// ------------------------------------------------------------------------------------------------
-// Geometry is a template parameter pair: T = owned tile edge, H = ghost ring = max steps per launch;
-// the region edge is R = T + 2H and the block has R*R lanes (<= 1024).
-constexpr int kMaxTileSteps = 8;
-
-template <int T, int H>
-struct TileGeom {
-  static constexpr int R = T + 2 * H;
-  static constexpr int lanes = R * R;
-  static constexpr int waves = (lanes + 63) / 64;
-  static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * lanes + sizeof(double) * H * waves;
-  static_assert(lanes <= 1024 && H <= kMaxTileSteps, "block too large");
-};
-
-struct TileArgs {
-  const float* src;
-  float* dst;
-  const uint32_t* mask;
-  size_t ps;
-  int nx, ny;
-  int tiles_x;                 // nx / T
-  int ksteps;                  // 1..H steps in this launch
-  float omega, accel_w1, accel_w2;
-  int accel_row;               // ny-2
-  int accel_last;              // apply accelerate_flow after the LAST sub-step too (another step follows)
-  double* partials_out;        // [ksteps][ntiles]
-  const double* prev_partials; // previous launch: [n_prev_vecs][n_prev]
-  int n_prev, n_prev_vecs;
-  double* sums;
-  int* counter;
-};
-
-template <int T, int H>
-__global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H)) lbm_tile_kernel(const TileArgs a)
-{
-  using G = TileGeom<T, H>;
-  constexpr int R = G::R, kLanes = G::lanes, kWaves = G::waves;
-  extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][9][lanes] floats, then reduction scratch
-  double* red = reinterpret_cast<double*>(lds + 2 * 9 * kLanes);    // [H][kWaves]
-  const int tid = threadIdx.x;
-
-  if (blockIdx.x == 0) {
-    // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
-    for (int v = 0; v < a.n_prev_vecs; ++v) {
-      double s = 0.0;
-      for (int i = tid; i < a.n_prev; i += kLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
-      s = wave_sum(s);
-      __syncthreads();
-      if ((tid & 63) == 0) red[tid >> 6] = s;
-      __syncthreads();
-      if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < kWaves; ++w) t += red[w];
-        a.sums[*a.counter + v] = t;
-      }
-    }
-    __syncthreads();
-    if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
-    return;
-  }
-
-  const int tile = blockIdx.x - 1;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int ry = tid / R, rx = tid - ry * R;
-  // global cell of this lane, periodic (d2q9-bgk.c:527-529 in x; :245-247 one-rank ring in y)
-  int gx = (tx * T - H + rx) % a.nx; if (gx < 0) gx += a.nx;
-  int gy = (ty * T - H + ry) % a.ny; if (gy < 0) gy += a.ny;
-  const int cell = gy * a.nx + gx;
-  const bool blocked = (a.mask[cell >> 5] >> (cell & 31)) & 1u;
-  const bool owned = rx >= H && rx < H + T && ry >= H && ry < H + T;
-  const bool on_accel_row = gy == a.accel_row;
-
-  float* bufA = lds;
-  float* bufB = lds + 9 * kLanes;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) bufA[k * kLanes + tid] = a.src[k * a.ps + cell];
-  __syncthreads();
-
-  double acc[H];
-#pragma unroll
-  for (int i = 0; i < H; ++i) acc[i] = 0.0;
-  float out[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) out[k] = 0.0f;
-
-  const int k_total = a.ksteps;
-#pragma unroll 1
-  for (int s = 1; s <= k_total; ++s) {
-    // cells still needed after this sub-step: the owned tile expanded by (k_total - s)
-    const int e = k_total - s;
-    const bool active = rx >= H - e && rx < H + T + e && ry >= H - e && ry < H + T + e;
-    if (active) {
-      float t[9], o[9];
-      const int here = tid, south = tid - R, north = tid + R;                   // d2q9-bgk.c:530-538
-      t[0] = bufA[0 * kLanes + here];
-      t[1] = bufA[1 * kLanes + here - 1];
-      t[2] = bufA[2 * kLanes + south];
-      t[3] = bufA[3 * kLanes + here + 1];
-      t[4] = bufA[4 * kLanes + north];
-      t[5] = bufA[5 * kLanes + south - 1];
-      t[6] = bufA[6 * kLanes + south + 1];
-      t[7] = bufA[7 * kLanes + north + 1];
-      t[8] = bufA[8 * kLanes + north - 1];
-      const double term = relax_cell(t, a.omega, o);
-      out[0] = blocked ? t[0] : o[0];                                          // bounce-back :687-695
-      out[1] = blocked ? t[3] : o[1];
-      out[2] = blocked ? t[4] : o[2];
-      out[3] = blocked ? t[1] : o[3];
-      out[4] = blocked ? t[2] : o[4];
-      out[5] = blocked ? t[7] : o[5];
-      out[6] = blocked ? t[8] : o[6];
-      out[7] = blocked ? t[5] : o[7];
-      out[8] = blocked ? t[6] : o[8];
-      if (owned && !blocked) {
-#pragma unroll
-        for (int i = 0; i < H; ++i)
-          if (i == s - 1) acc[i] = term;
-      }
-      // accelerate_flow of the following step (d2q9-bgk.c:457-469)
-      if (on_accel_row && !blocked && (s < k_total || a.accel_last) && out[3] - a.accel_w1 > 0.0f &&
-          out[6] - a.accel_w2 > 0.0f && out[7] - a.accel_w2 > 0.0f) {
-        out[1] += a.accel_w1; out[5] += a.accel_w2; out[8] += a.accel_w2;
-        out[3] -= a.accel_w1; out[6] -= a.accel_w2; out[7] -= a.accel_w2;
-      }
-      if (s < k_total) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) bufB[k * kLanes + tid] = out[k];
-      }
-    }
-    __syncthreads();
-    float* sw = bufA; bufA = bufB; bufB = sw;
-  }
-
-  if (owned) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a.dst[k * a.ps + cell] = out[k];
-  }
-
-  // per-step sums over the owned cells of this tile: wave trees, then one lane per step over the waves
-  const int ntiles = gridDim.x - 1;
-#pragma unroll
-  for (int i = 0; i < H; ++i) {
-    const double w = wave_sum(acc[i]);
-    if ((tid & 63) == 0) red[i * kWaves + (tid >> 6)] = w;
-  }
-  __syncthreads();
-  if (tid < k_total) {
-    double t = 0.0;
-    for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
-    a.partials_out[static_cast<size_t>(tid) * ntiles + tile] = t;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K steps per pass over HBM for bandwidth-bound grids: lbm_multi_kernel<K>.
-//
-// The one-step kernel moves 72 B per cell-step and sits at ~90 % of what HBM delivers; the only way
-// further up is to touch memory less often.  Here a 512-lane block owns a 64x16 tile and advances it
-// by up to K steps per launch: sub-step 1 pulls straight from the source grid (as the one-step kernel
-// does) for the tile plus a (K-1)-cell ring and keeps the result in LDS; sub-steps 2..K update that
-// LDS frame in place (neighbours read into registers, barrier, results written back), each on a
-// region one cell smaller; the last sub-step covers exactly the owned tile and writes the
-// destination grid.  The ring is recomputed redundantly by the neighbouring blocks with the same
-// arithmetic, so no block ever waits for another, and the results are bit-identical to K launches of
-// the one-step kernel.  HBM traffic per K steps: (64+2K)(16+2K)/1024 x 36 B read + 36 B written
-// (K = 2: 84 B instead of 144 B; K = 4: 97 B instead of 288 B).
-//
-// Rows outside the partition: `y_periodic` wraps (self-contained domain); otherwise the storage has
-// `ghost` extra rows below and above the owned rows, filled by the neighbours before the launch.
-// ------------------------------------------------------------------------------------------------
-constexpr int kMTX = 64, kMTY = 16, kMLanes = 512, kMaxMultiSteps = 4;
-
-// Sub-step j of k (1-based) works on the owned tile grown by (k-j) rows and 2(k-j) columns on each
-// side: columns grow twice as fast so that every region starts on an even x and a lane can own an
-// x-PAIR of cells (8-byte accesses; the two cells' arithmetic is packed by the compiler into
-// v_pk_*_f32, which halves the instruction count - the one-cell form of this kernel was VALU-bound).
-template <int K>
-struct MultiGeom {
-  static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
-  static constexpr int W = kMTX + 2 * EX, H = kMTY + 2 * EY;        // LDS frame
-  static constexpr int cells = W * H;
-  static constexpr int pairs2 = K >= 2 ? ((kMTX + 4 * (K - 2)) / 2) * (kMTY + 2 * (K - 2)) : 0;   // largest in-LDS region
-  static constexpr int passes = (pairs2 + kMLanes - 1) / kMLanes;
-  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64);
-};
-
-struct MultiArgs {
-  const float* src;
-  float* dst;
-  const uint32_t* mask;        // bit per STORAGE cell (ghost rows included)
-  size_t ps;
-  int nx;
-  int rows_owned;              // owned rows
-  int ghost;                   // storage rows before the first owned row (0 when y_periodic)
-  int y_periodic;
-  int y0_global, ny_global;    // global row of the first owned row; global grid height
-  int tiles_x;
-  int tile_begin, tile_count, tile_begin2, tile_count2;   // tile ranges of this launch (second may be empty)
-  int ntiles_total;            // stride of partials_out
-  int ksteps;                  // 1..K steps in this launch
-  int xcd_remap;               // tile order: contiguous eighth per XCD (needs (tile_count+tile_count2) % 8 == 0)
-  float omega, accel_w1, accel_w2;
-  int accel_row;               // GLOBAL row ny-2
-  int accel_last;
-  double* partials_out;        // [ksteps][ntiles_total]
-  const double* prev_partials; // previous launch: [n_prev_vecs][n_prev]
-  int n_prev, n_prev_vecs;
-  double* sums;
-  int* counter;
-};
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-
-__device__ __forceinline__ void bounce_or_relax(const float (&t)[9], const float (&o)[9], bool blocked, float (&out)[9])
-{
-  out[0] = blocked ? t[0] : o[0];                                       // bounce-back d2q9-bgk.c:687-695
-  out[1] = blocked ? t[3] : o[1];
-  out[2] = blocked ? t[4] : o[2];
-  out[3] = blocked ? t[1] : o[3];
-  out[4] = blocked ? t[2] : o[4];
-  out[5] = blocked ? t[7] : o[5];
-  out[6] = blocked ? t[8] : o[6];
-  out[7] = blocked ? t[5] : o[7];
-  out[8] = blocked ? t[6] : o[8];
-}
-
-__device__ __forceinline__ void accelerate_cell(float (&out)[9], float w1, float w2)   // d2q9-bgk.c:457-469
-{
-  if (out[3] - w1 > 0.0f && out[6] - w2 > 0.0f && out[7] - w2 > 0.0f) {
-    out[1] += w1; out[5] += w2; out[8] += w2;
-    out[3] -= w1; out[6] -= w2; out[7] -= w2;
-  }
-}
-
-// Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
-// p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
-// Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
-// double-precision sqrt is a tenth of the cell's instructions).
-__device__ __forceinline__ double finish_pair(const f2 (&p)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
-                                              bool want_term, f2 (&out)[9])
-{
-  float msq[2], rinv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float t[9], o[9], r[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = p[k][j];
-    relax_cell_core(t, omega, o, msq[j], rinv[j]);
-    const bool blocked = (mbits >> j) & 1u;
-    bounce_or_relax(t, o, blocked, r);
-    if (accel && !blocked) accelerate_cell(r, w1, w2);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) out[k][j] = r[k];
-  }
-  double term = 0.0;
-  if (want_term) {
-    const double t0 = sqrt(static_cast<double>(msq[0])) * static_cast<double>(rinv[0]);   // :667
-    const double t1 = sqrt(static_cast<double>(msq[1])) * static_cast<double>(rinv[1]);
-    term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
-  }
-  return term;
-}
-
-template <int K, bool FULL>   // FULL: this launch does exactly K steps (all region sizes are compile-time constants)
-__global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
-{
-  using G = MultiGeom<K>;
-  constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
-  double* red = reinterpret_cast<double*>(lds + 9 * kCells);
-  const int tid = threadIdx.x;
-
-  if (blockIdx.x == 0) {
-    // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
-    for (int v = 0; v < a.n_prev_vecs; ++v) {
-      double s = 0.0;
-      for (int i = tid; i < a.n_prev; i += kMLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
-      s = wave_sum(s);
-      __syncthreads();
-      if ((tid & 63) == 0) red[tid >> 6] = s;
-      __syncthreads();
-      if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < kWaves; ++w) t += red[w];
-        a.sums[*a.counter + v] = t;
-      }
-    }
-    __syncthreads();
-    if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
-    return;
-  }
-
-  int b = blockIdx.x - 1;
-  if (a.xcd_remap) {
-    // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD one contiguous eighth of
-    // the launch so that tiles which overlap (x and y neighbours) meet in the same L2
-    const int nb = gridDim.x - 1, per = nb >> 3;
-    b = (b & 7) * per + (b >> 3);
-  }
-  const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int x0 = tx * kMTX;
-  const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
-  const size_t ps = a.ps;
-  const int nx = a.nx;
-  const int rows_storage = a.rows_owned + 2 * a.ghost;
-  const int ksteps = FULL ? K : a.ksteps;
-  double acc[K];
-#pragma unroll
-  for (int i = 0; i < K; ++i) acc[i] = 0.0;
-
-  // storage row -> does it hold the global accelerate row ny-2 ?
-  auto on_accel_row = [&](int sr) {
-    int g = a.y0_global + sr - a.ghost;
-    if (g < 0) g += a.ny_global; else if (g >= a.ny_global) g -= a.ny_global;
-    return g == a.accel_row;
-  };
-
-  // ---- sub-step 1: pull from the source grid; region = owned tile grown by (ksteps-1) rows / 2(ksteps-1) columns
-  {
-    const int ey = ksteps - 1, ex = 2 * ey;
-    const int wp = (kMTX + 2 * ex) / 2;                                 // pairs per region row
-    const int np = wp * (kMTY + 2 * ey);
-#pragma unroll 1
-    for (int i = tid; i < np; i += kMLanes) {
-      const int ry = i / wp, rp = i - ry * wp;
-      const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
-      int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;            // periodic (:527-529)
-      int sr = sy0 + fy - EY;
-      int ys = sr - 1, yn = sr + 1;
-      if (a.y_periodic) {                                                                 // periodic (:245-247)
-        if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
-        ys = (sr == 0) ? rows_storage - 1 : sr - 1;
-        yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
-      }
-      const float* here = a.src + static_cast<size_t>(sr) * nx + gx;
-      const float* south = a.src + static_cast<size_t>(ys) * nx + gx;
-      const float* north = a.src + static_cast<size_t>(yn) * nx + gx;
-      f2 p[9];
-      p[0] = *reinterpret_cast<const f2*>(here);                                           // :530
-      p[2] = *reinterpret_cast<const f2*>(south + 2 * ps);                                 // :532
-      p[4] = *reinterpret_cast<const f2*>(north + 4 * ps);                                 // :534
-      p[1] = *reinterpret_cast<const f2u*>(here + ps - 1);                                 // :531
-      p[5] = *reinterpret_cast<const f2u*>(south + 5 * ps - 1);                            // :535
-      p[8] = *reinterpret_cast<const f2u*>(north + 8 * ps - 1);                            // :538
-      p[3] = *reinterpret_cast<const f2u*>(here + 3 * ps + 1);                             // :533
-      p[6] = *reinterpret_cast<const f2u*>(south + 6 * ps + 1);                            // :536
-      p[7] = *reinterpret_cast<const f2u*>(north + 7 * ps + 1);                            // :537
-      if (gx == 0) {                          // x_w wraps to nx-1 (:529)
-        p[1].x = here[ps + nx - 1]; p[5].x = south[5 * ps + nx - 1]; p[8].x = north[8 * ps + nx - 1];
-      }
-      if (gx == nx - 2) {                     // x_e wraps to 0 (:527-528)
-        p[3].y = here[3 * ps + 2 - nx]; p[6].y = south[6 * ps + 2 - nx]; p[7].y = north[7 * ps + 2 - nx];
-      }
-      const int cell = sr * nx + gx;
-      const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
-      f2 out[9];
-      const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
-      acc[0] += finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
-      if (ksteps > 1) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], reinterpret_cast<f2*>(a.dst + k * ps + cell));
-      }
-    }
-  }
-  if constexpr (K >= 2) {
-    __syncthreads();
-    // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller
-#pragma unroll 1
-    for (int j = 2; j <= ksteps; ++j) {
-      const int ey = ksteps - j, ex = 2 * ey;
-      const int wp = (kMTX + 2 * ex) / 2;
-      const int np = wp * (kMTY + 2 * ey);
-      const bool last = j == ksteps;
-      f2 outs[G::passes][9];
-      int slot[G::passes];
-#pragma unroll
-      for (int q = 0; q < G::passes; ++q) {
-        const int i = tid + q * kMLanes;
-        slot[q] = -1;
-        if (i < np) {
-          const int ry = i / wp, rp = i - ry * wp;
-          const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;
-          const int c = fy * W + fx;
-          f2 p[9];
-          p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + c);
-          p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + c - W);
-          p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + c + W);
-          p[1] = f2{lds[1 * kCells + c - 1], lds[1 * kCells + c]};
-          p[5] = f2{lds[5 * kCells + c - W - 1], lds[5 * kCells + c - W]};
-          p[8] = f2{lds[8 * kCells + c + W - 1], lds[8 * kCells + c + W]};
-          p[3] = f2{lds[3 * kCells + c + 1], lds[3 * kCells + c + 2]};
-          p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
-          p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
-          int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;
-          int sr = sy0 + fy - EY;
-          if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
-          const int cell = sr * nx + gx;
-          const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
-          const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
-          const double term = finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
-                                          owned, outs[q]);
-#pragma unroll
-          for (int m = 1; m < K; ++m)
-            if (m == j - 1) acc[m] += term;
-          slot[q] = last ? cell : c;
-        }
-      }
-      if (!last) {
-        __syncthreads();                       // every lane has read its neighbours
-#pragma unroll
-        for (int q = 0; q < G::passes; ++q)
-          if (slot[q] >= 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + slot[q]) = outs[q][k];
-          }
-        __syncthreads();
-      } else {
-#pragma unroll
-        for (int q = 0; q < G::passes; ++q)
-          if (slot[q] >= 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[q][k], reinterpret_cast<f2*>(a.dst + k * ps + slot[q]));
-          }
-      }
-    }
-  }
-
-  // per-step sums over the owned cells of this tile
-#pragma unroll
-  for (int q = 0; q < K; ++q) {
-    const double w = wave_sum(acc[q]);
-    if ((tid & 63) == 0) red[q * kWaves + (tid >> 6)] = w;
-  }
-  __syncthreads();
-  if (tid < ksteps) {
-    double t = 0.0;
-    for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
-    a.partials_out[static_cast<size_t>(tid) * a.ntiles_total + tile] = t;
-  }
-}
-
-// Folds the last step's partials after the loop.
-__global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, int nvecs, double* sums, int* counter)
-{
-  __shared__ double red[kBlock / 64];
-  for (int v = 0; v < nvecs; ++v) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += kBlock) s += partials[static_cast<size_t>(v) * n + i];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) sums[*counter + v] = s;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *counter += nvecs;
-}
-
-// accelerate_flow (d2q9-bgk.c:442-478) in place on one row: only needed before the first step of a run.
-__global__ void lbm_accelerate_kernel(float* grid, size_t ps, const uint32_t* mask, int nx, int row, float w1, float w2)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= nx) return;
-  const size_t c = static_cast<size_t>(row) * nx + x;
-  if ((mask[c >> 5] >> (c & 31)) & 1u) return;
-  float* f = grid + c;
-  const float f3 = f[3 * ps], f6 = f[6 * ps], f7 = f[7 * ps];
-  if (f3 - w1 > 0.0f && f6 - w2 > 0.0f && f7 - w2 > 0.0f) {
-    f[1 * ps] += w1; f[5 * ps] += w2; f[8 * ps] += w2;
-    f[3 * ps] = f3 - w1; f[6 * ps] = f6 - w2; f[7 * ps] = f7 - w2;
-  }
-}
-
-// Initial state (d2q9-bgk.c:880-902).
-__global__ void lbm_init_kernel(float* grid, size_t ps, size_t ncells, float w0, float w1, float w2)
-{
-  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= ncells) return;
-  grid[i] = w0;
-#pragma unroll
-  for (int k = 1; k < 5; ++k) grid[k * ps + i] = w1;
-#pragma unroll
-  for (int k = 5; k < 9; ++k) grid[k * ps + i] = w2;
-}
-
-// AoS (reference t_speed) <-> SoA planes.
-__global__ void lbm_aos_to_soa_kernel(const float* aos, float* grid, size_t ps, size_t ncells)
-{
-  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= ncells * 9) return;
-  const size_t c = i / 9;
-  const int k = static_cast<int>(i - c * 9);
-  grid[k * ps + c] = aos[i];
-}
-
-__global__ void lbm_soa_to_aos_kernel(const float* grid, float* aos, size_t ps, size_t ncells)
-{
-  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= ncells * 9) return;
-  const size_t c = i / 9;
-  const int k = static_cast<int>(i - c * 9);
-  aos[i] = grid[k * ps + c];
-}
-
-// Outgoing halo rows of the CURRENT grid (before the first step of a row-partitioned run).
-__global__ void lbm_pack_halo_kernel(const float* grid, size_t ps, int nx, int nyl, int nxp, float* send_south, float* send_north)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= nx) return;
-  const float* first = grid + x;
-  const float* last = grid + static_cast<size_t>(nyl - 1) * nx + x;
-  float* ss = send_south + kHaloGuard + x;
-  float* sn = send_north + kHaloGuard + x;
-  ss[0] = first[4 * ps]; ss[nxp] = first[7 * ps]; ss[2 * nxp] = first[8 * ps];
-  sn[0] = last[2 * ps];  sn[nxp] = last[5 * ps];  sn[2 * nxp] = last[6 * ps];
-}
-
-// av_velocity (d2q9-bgk.c:716-751): per-cell float arithmetic as the reference, double accumulation.
-__global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t ncells, double* partials)
-{
-  __shared__ double red[kBlock / 64];
-  double acc = 0.0;
-  for (size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; c < ncells; c += static_cast<size_t>(gridDim.x) * kBlock) {
-    if ((mask[c >> 5] >> (c & 31)) & 1u) continue;
-    float f[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) f[k] = grid[k * ps + c];
-    float rho = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) rho += f[k];                                   // :724-729
-    const float ux = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;        // :732-738
-    const float uy = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;        // :740-746
-    acc += sqrt(static_cast<double>((ux * ux) + (uy * uy)));                   // :748
-  }
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
 
 // ------------------------------------------------------------------------------------------------
 // host side of the device ABI
