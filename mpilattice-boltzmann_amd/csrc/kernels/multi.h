@@ -67,26 +67,61 @@ struct MultiArgs {
 // p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
 // Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
 // double-precision sqrt is a tenth of the cell's instructions).
-__device__ __forceinline__ double finish_pair(const f2 (&p)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
+__device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
                                               bool want_term, f2 (&out)[9])
 {
-  float msq[2], rinv[2];
+  // relax_cell_core on both cells at once: every line is the scalar line with f2 operands, so each
+  // component sees exactly the reference's operation order (d2q9-bgk.c:546-666) and hipcc emits
+  // packed v_pk_add_f32 / v_pk_mul_f32 for all of it.
+  const f2 csq_inv = {3.0f, 3.0f};                                     // :497
+  const float w0 = 4.0f / 9.0f, wa = 1.0f / 9.0f, wd = 1.0f / 36.0f;   // :499-501
+  f2 rho = t[0];                                                       // :546-554
+  rho += t[1]; rho += t[2]; rho += t[3]; rho += t[4];
+  rho += t[5]; rho += t[6]; rho += t[7]; rho += t[8];
+  f2 rinv;                                                             // :561 (correctly rounded division per cell)
+  rinv.x = 1.0f / rho.x; rinv.y = 1.0f / rho.y;
+  f2 mx = t[1] + t[5];                                                 // :570-574
+  mx += t[8]; mx -= t[3]; mx -= t[6]; mx -= t[7];
+  f2 my = t[2] + t[5];                                                 // :576-580
+  my += t[6]; my -= t[4]; my -= t[7]; my -= t[8];
+  const f2 msq = mx * mx + my * my;                                    // :589
+  f2 e[9];
+  e[1] = mx;        e[2] = my;         e[3] = -mx;        e[4] = -my;          // :596-599
+  e[5] = mx + my;   e[6] = -mx + my;   e[7] = -mx - my;   e[8] = mx - my;      // :600-603
+  const f2 half = {0.5f, 0.5f};
+  const f2 h = half * rinv * csq_inv;                                  // "0.5f*densinv*ic_sq" of :638-646
+  const f2 om = {omega, omega};
+  f2 o[9];
+  {
+    const f2 wv = {w0, w0};
+    const f2 q0 = wv * (rho - h * msq);                                // :638
+    o[0] = t[0] + om * (q0 - t[0]);                                    // :658
+  }
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const f2 a = e[k] * csq_inv;                                       // :610-617
+    const f2 b = a * e[k];                                             // :624-631
+    const float wk = (k < 5) ? wa : wd;
+    const f2 wv = {wk, wk};
+    const f2 q = wv * (rho + a + h * (b - msq));                       // :639-646
+    o[k] = t[k] + om * (q - t[k]);                                     // :659-666
+  }
+  // bounce-back select (d2q9-bgk.c:687-695) and the next step's accelerate_flow (:457-469), per cell
+  static constexpr int opp[9] = {0, 3, 4, 1, 2, 7, 8, 5, 6};
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    float t[9], o[9], r[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = p[k][j];
-    relax_cell_core(t, omega, o, msq[j], rinv[j]);
     const bool blocked = (mbits >> j) & 1u;
-    bounce_or_relax(t, o, blocked, r);
+    float r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = blocked ? t[opp[k]][j] : o[k][j];
     if (accel && !blocked) accelerate_cell(r, w1, w2);
 #pragma unroll
     for (int k = 0; k < 9; ++k) out[k][j] = r[k];
   }
   double term = 0.0;
   if (want_term) {
-    const double t0 = sqrt(static_cast<double>(msq[0])) * static_cast<double>(rinv[0]);   // :667
-    const double t1 = sqrt(static_cast<double>(msq[1])) * static_cast<double>(rinv[1]);
+    const double t0 = sqrt(static_cast<double>(msq.x)) * static_cast<double>(rinv.x);   // :667
+    const double t1 = sqrt(static_cast<double>(msq.y)) * static_cast<double>(rinv.y);
     term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
   }
   return term;
