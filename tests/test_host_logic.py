@@ -174,3 +174,15 @@ def test_synthetic_deck_is_reproducible(lbm, tmp_path):
     obst, free = lbm.read_obstacles(op, 64, 32)
     assert np.array_equal(obst, a) and free == 64 * 32 - a.sum()
     assert lbm.read_params(pp).max_iters == 5
+
+
+def test_front_ends_parse_arguments_without_a_gpu():
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "d2q9_bgk.py")], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Usage: ") and r.stderr.rstrip().endswith("<paramfile> <obstaclefile>")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "d2q9_bgk.py"), "/nonexistent.params", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "could not open input parameter file: /nonexistent.params" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "check", "check.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--ref-av-vels-file" in r.stdout
