@@ -399,13 +399,16 @@ class Simulation:
     """paramfile + obstaclefile -> av_vels, final state, Reynolds number (the reference's `main`).
 
     With a torch.distributed process group of size > 1 (one process per GPU), each rank owns the
-    rows `decompose()` gives it and `run()` performs the halo exchange over the group; otherwise the
-    whole grid lives on one GPU and `run()` is a single `lbm_run`."""
+    rows `decompose()` gives it and `run()` performs the halo exchange over the group — by default in
+    the native RCCL loop, K steps per exchange where the partition is eligible (`lbm_create_global`,
+    `Partition.macro_steps`); otherwise the whole grid lives on one GPU and `run()` is one `lbm_run`."""
 
     def __init__(self, params: Params, obstacles: np.ndarray, *, device: int = 0, flags: int = 0,
                  distributed: bool = False, group=None, exchange: str = "rccl"):
         """exchange: how a distributed run moves its halos — "rccl" = the native loop of
         liblbm_d2q9_rccl.so (default), "torch" = torch.distributed P2P ops from Python."""
+        if exchange not in ("rccl", "torch"):
+            raise ValueError("exchange must be 'rccl' or 'torch'")
         obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
         if obstacles.shape != (params.ny, params.nx):
             raise ValueError("obstacles must be (ny, nx)")
@@ -429,8 +432,6 @@ class Simulation:
         self._torch_device = None
         self._stream = None
         self._ring: Optional[RcclRing] = None
-        if exchange not in ("rccl", "torch"):
-            raise ValueError("exchange must be 'rccl' or 'torch'")
         # a forced-halo whole-grid partition is a 1-rank ring that exchanges with itself (:245-247)
         self._partitioned = self.size > 1 or bool(flags & _capi.FLAG_FORCE_HALO)
         if self._partitioned and not distributed:
