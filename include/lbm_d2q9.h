@@ -149,6 +149,14 @@ int    lbm_macro_steps(const lbm_ctx* ctx);
 size_t lbm_macro_halo_floats(const lbm_ctx* ctx);
 void*  lbm_macro_send_ptr(lbm_ctx* ctx, int dir, int plane);
 void*  lbm_macro_recv_ptr(lbm_ctx* ctx, int dir, int plane);
+/* Packed exchange (2 messages per direction instead of 18): lbm_macro_pack gathers the outgoing rows of
+ * all planes into lbm_macro_pack_ptr(dir, 0) (lbm_macro_pack_floats() floats per direction), the caller
+ * moves them into the neighbours' lbm_macro_pack_ptr(dir, 1), lbm_macro_unpack scatters those into the
+ * ghost rows.  dir of an incoming buffer = the side it came from (0 = from the south neighbour). */
+size_t lbm_macro_pack_floats(const lbm_ctx* ctx);
+void*  lbm_macro_pack_ptr(lbm_ctx* ctx, int dir, int incoming);
+int    lbm_macro_pack(lbm_ctx* ctx, void* stream);
+int    lbm_macro_unpack(lbm_ctx* ctx, void* stream);
 int    lbm_macro_prepare(lbm_ctx* ctx, int n_steps, void* stream);
 int    lbm_macro_interior(lbm_ctx* ctx, void* stream);
 int    lbm_macro_edge(lbm_ctx* ctx, void* stream);

@@ -57,6 +57,10 @@ _SIGNATURES = {
     "lbm_macro_halo_floats": (C.c_size_t, [_ctx]),
     "lbm_macro_send_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
     "lbm_macro_recv_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
+    "lbm_macro_pack_floats": (C.c_size_t, [_ctx]),
+    "lbm_macro_pack_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
+    "lbm_macro_pack": (C.c_int, [_ctx, C.c_void_p]),
+    "lbm_macro_unpack": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_prepare": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
     "lbm_macro_interior": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_edge": (C.c_int, [_ctx, C.c_void_p]),

@@ -78,6 +78,20 @@ __global__ void lbm_pack_halo_kernel(const float* grid, size_t ps, int nx, int n
   sn[0] = last[2 * ps];  sn[nxp] = last[5 * ps];  sn[2 * nxp] = last[6 * ps];
 }
 
+// K-step row partitions: gather the K first / last owned rows of all 9 planes into one contiguous
+// message per direction (pack), and scatter the two received messages into the ghost rows (unpack).
+// buf layout: [dir][plane][K*nx].  rows_a / rows_b = storage row where direction 0 / 1's K rows start.
+__global__ void lbm_macro_pack_kernel(const float* grid, float* buf, size_t ps, int nfloats /* K*nx */, size_t row_a, size_t row_b, int nx, int unpack)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // float4 index within one plane's K rows
+  const int plane = blockIdx.y, dir = blockIdx.z;
+  if (i * 4 >= nfloats) return;
+  const size_t goff = plane * ps + (dir == 0 ? row_a : row_b) * nx + static_cast<size_t>(i) * 4;
+  const size_t boff = (static_cast<size_t>(dir) * 9 + plane) * nfloats + static_cast<size_t>(i) * 4;
+  if (unpack) *reinterpret_cast<f4*>(const_cast<float*>(grid) + goff) = *reinterpret_cast<const f4*>(buf + boff);
+  else *reinterpret_cast<f4*>(buf + boff) = *reinterpret_cast<const f4*>(grid + goff);
+}
+
 // av_velocity (d2q9-bgk.c:716-751): per-cell float arithmetic as the reference, double accumulation.
 __global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t ncells, double* partials)
 {

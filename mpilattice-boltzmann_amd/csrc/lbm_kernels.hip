@@ -104,6 +104,7 @@ struct lbm_ctx {
   int lane_cells = kCellsPerLane;   // cells per lane: 4 (vector form) or 1 (narrow form: tiny grids, nx % 4 != 0)
   int nxp = 0;
   float* halo_alloc = nullptr;
+  float* macro_pack[2] = {nullptr, nullptr};   // K-step mode: packed outgoing / incoming messages, [dir][plane][K*nx] each
   float* send[2] = {nullptr, nullptr};
   float* recv[2] = {nullptr, nullptr};
   double* partials[2] = {nullptr, nullptr};
@@ -454,6 +455,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->tile_kernel = self_periodic && c->n_tiles > 0 &&
                    c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 65536));   // 512x512: lbm_multi_kernel<3> 3.5 us/step vs 5.2 here
   if (c->ghost > 0) {
+    const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
+    for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
     c->multi_tiles_x = p->nx / kMTX;
     c->multi_tiles = c->multi_tiles_x * (ny_local / kMTY);
@@ -516,6 +519,7 @@ int lbm_destroy(lbm_ctx* c)
   for (int g = 0; g < 2; ++g) if (c->grid_alloc[g]) (void)hipFree(c->grid_alloc[g]);
   if (c->mask) (void)hipFree(c->mask);
   if (c->halo_alloc) (void)hipFree(c->halo_alloc);
+  for (float* b : c->macro_pack) if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) if (c->partials[i]) (void)hipFree(c->partials[i]);
   if (c->sums) (void)hipFree(c->sums);
   if (c->counter) (void)hipFree(c->counter);
@@ -779,6 +783,41 @@ void* lbm_macro_recv_ptr(lbm_ctx* c, int dir, int plane)
   // ghost rows below the first owned row come from the south, those above the last one from the north
   const size_t row = dir == 0 ? 0 : static_cast<size_t>(c->ghost + c->nyl);
   return c->grid[c->cur] + plane * c->ps + row * c->p.nx;
+}
+
+// Packed form of the exchange: 2 messages per direction instead of 18.
+size_t lbm_macro_pack_floats(const lbm_ctx* c) { return (c && c->ghost > 0) ? static_cast<size_t>(9) * c->ghost * c->p.nx : 0; }
+
+void* lbm_macro_pack_ptr(lbm_ctx* c, int dir, int incoming)
+{
+  if (!c || c->ghost == 0 || (dir != 0 && dir != 1)) return nullptr;
+  return c->macro_pack[incoming ? 1 : 0] + static_cast<size_t>(dir) * lbm_macro_pack_floats(c);
+}
+
+static int macro_pack_launch(lbm_ctx* c, bool unpack, hipStream_t s)
+{
+  const int nfloats = c->ghost * c->p.nx;
+  const dim3 grid((nfloats / 4 + 255) / 256, 9, 2);
+  // outgoing: first K owned rows (dir 0, south) and last K owned rows (dir 1, north);
+  // incoming: ghost rows below (from the south, dir 0) and above (from the north, dir 1)
+  const size_t row_a = unpack ? 0 : static_cast<size_t>(c->ghost);
+  const size_t row_b = unpack ? static_cast<size_t>(c->ghost + c->nyl) : static_cast<size_t>(c->nyl);
+  hipLaunchKernelGGL(lbm_macro_pack_kernel, grid, dim3(256), 0, s, c->grid[c->cur], c->macro_pack[unpack ? 1 : 0], c->ps, nfloats,
+                     row_a, row_b, c->p.nx, unpack ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int lbm_macro_pack(lbm_ctx* c, void* stream)
+{
+  if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_pack: not a K-step context"); return 1; }
+  return macro_pack_launch(c, false, pick_stream(c, stream));
+}
+
+int lbm_macro_unpack(lbm_ctx* c, void* stream)
+{
+  if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_unpack: not a K-step context"); return 1; }
+  return macro_pack_launch(c, true, pick_stream(c, stream));
 }
 
 int lbm_macro_prepare(lbm_ctx* c, int n_steps, void* stream)

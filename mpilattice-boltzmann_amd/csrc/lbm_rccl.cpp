@@ -134,13 +134,17 @@ int lbm_comm_destroy(lbm_comm* c)
 }
 
 // K-step mode (contexts from lbm_create_global, lbm_macro_steps() = K > 0): one exchange of K whole rows
-// of each of the 9 planes per K steps, same three-queue schedule; messages go straight from the
-// sender's edge rows into the receiver's ghost rows (no staging buffers).
+// of each of the 9 planes per K steps, same three-queue schedule.  By default the 18 row blocks of a
+// direction pair are packed into one message per direction by a small kernel on the exchange stream
+// (fewer, larger messages); LBM_RCCL_PACK=0 sends them straight from the edge rows into the
+// neighbour's ghost rows as 18 + 18 messages.
 static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
 {
   lbm_ctx* ctx = c->ctx;
   const int K = lbm_macro_steps(ctx);
-  const size_t n = lbm_macro_halo_floats(ctx);
+  const size_t n = lbm_macro_halo_floats(ctx), np = lbm_macro_pack_floats(ctx);
+  const char* pk = std::getenv("LBM_RCCL_PACK");
+  const bool packed = !(pk && pk[0] == '0');              // default: 2 + 2 packed messages; 0 = 18 + 18 direct ones
   const bool three_queues = c->three_queues;
   hipStream_t edge_stream = three_queues ? c->edge : c->compute;
   LBM_TRY(lbm_macro_prepare(ctx, n_steps, c->compute));   // step-0 accelerate_flow
@@ -148,14 +152,26 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
   HIP_TRY(hipEventRecord(c->interior_done, c->compute));
   for (int done = 0; done < n_steps; done += K) {
     HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));   // the rows to send were written by the last edge launch
-    NCCL_TRY(ncclGroupStart());
-    for (int k = 0; k < LBM_NSPEEDS; ++k) {                  // order as in the one-step loop: sends [S, N], receives [N, S]
-      NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
-      NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
-      NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
-      NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
+    if (packed) {
+      // gather the 9 planes' rows into one message per direction, exchange 2 + 2 messages, scatter
+      LBM_TRY(lbm_macro_pack(ctx, c->side));
+      NCCL_TRY(ncclGroupStart());                            // order as in the one-step loop: sends [S, N], receives [N, S]
+      NCCL_TRY(ncclSend(lbm_macro_pack_ptr(ctx, 0, 0), np, ncclFloat, c->south, c->nccl, c->side));
+      NCCL_TRY(ncclSend(lbm_macro_pack_ptr(ctx, 1, 0), np, ncclFloat, c->north, c->nccl, c->side));
+      NCCL_TRY(ncclRecv(lbm_macro_pack_ptr(ctx, 1, 1), np, ncclFloat, c->north, c->nccl, c->side));
+      NCCL_TRY(ncclRecv(lbm_macro_pack_ptr(ctx, 0, 1), np, ncclFloat, c->south, c->nccl, c->side));
+      NCCL_TRY(ncclGroupEnd());
+      LBM_TRY(lbm_macro_unpack(ctx, c->side));
+    } else {
+      NCCL_TRY(ncclGroupStart());
+      for (int k = 0; k < LBM_NSPEEDS; ++k) {                // rows straight into the neighbour's ghost rows
+        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
+        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
+        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
+        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
+      }
+      NCCL_TRY(ncclGroupEnd());
     }
-    NCCL_TRY(ncclGroupEnd());
     HIP_TRY(hipEventRecord(c->halo, c->side));
     if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
     LBM_TRY(lbm_macro_interior(ctx, c->compute));
