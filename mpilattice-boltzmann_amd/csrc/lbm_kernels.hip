@@ -355,9 +355,11 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
   if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && p->nx % kMTX == 0 && ny_local % kMTY == 0 &&
       ny_local >= 2 * kMTY) {
-    // measured on a 1-rank ring (us/step; one-step loop 116 / 37): 8192x1024 rows K=2 108, K=3 71, K=4 74;
-    // 1024x128 rows K=2 44, K=3 30, K=4 25 -- the exchange (36 messages) costs ~50 us per macro-step
-    const int k = tune_env("LBM_TUNE_MACRO_K", c->ncells < (1u << 21) ? 4 : 3);
+    // measured on a 1-rank ring with the packed exchange, us/step for K = 2 / 3 / 4 (one-step loop):
+    //   8192x4096 rows 247 / 255 / 268   8192x1024 rows 72.5 / 70.1 / 72.3 (116)   1024x512 rows 25.7 / 17.6 / 15.0
+    //   1024x128 rows 25.0 / 18.4 / 14.4 (37)
+    const int by_size = c->ncells < (1u << 21) ? 4 : (c->ncells < (1u << 24) ? 3 : 2);
+    const int k = tune_env("LBM_TUNE_MACRO_K", by_size);
     if (k > 0) { c->multi_K = std::min(k, kMaxMultiSteps); c->ghost = c->multi_K; }
   }
   c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
