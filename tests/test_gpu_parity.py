@@ -246,7 +246,30 @@ def test_full_size_8192_properties_and_short_parity(lbm, oracle):
                                  + 4 * np.float64(np.float32(0.1) / np.float32(36.0)))
     assert abs(mass - mass0) / mass0 < 1e-6
     assert np.all(av > 0) and np.all(np.diff(av) > 0)
-    ref_cells, _, ref_exact = oracle.run(p, obst, 12, nthreads=os.cpu_count() or 8)
+    ref_cells, _, ref_exact = oracle.run(p, obst, 12, nthreads=min(os.cpu_count() or 8, 16))
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    del cells
+    # the same deck as a K-step row partition on a 1-rank RCCL ring (what each rank of an N-GPU run executes)
+    ring = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    assert ring.partition.macro_steps >= 2
+    av_ring = ring.run(12)
+    assert np.array_equal(bits(ring.local_cells()), bits(ref_cells))
+    assert np.max(np.abs(av_ring - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    ring.close()
+
+
+def test_mid_size_longer_run(lbm, oracle):
+    """2048x2048 synthetic deck, 300 steps: lbm_multi_kernel on a grid well past the caches."""
+    n = 2048
+    p = lbm.Params(n, n, 300, 10, 0.1, 0.005, 1.85)
+    obst = lbm.synthetic_obstacles(n, n, 0.005, 42, True)
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"].startswith("lbm_multi_kernel")
+    av = s.run(300)
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 300, nthreads=min(os.cpu_count() or 8, 16))
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
