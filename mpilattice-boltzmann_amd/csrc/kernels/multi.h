@@ -235,8 +235,7 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
   if constexpr (K >= 2) {
     __syncthreads();
     // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller
-#pragma unroll 1
-    for (int j = 2; j <= ksteps; ++j) {
+    auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
       const int ey = ksteps - j, ex = 2 * ey;
       const int wp = (kMTX + 2 * ex) / 2;
       const int np = wp * (kMTY + 2 * ey);
@@ -292,6 +291,13 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
             for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[q][k], reinterpret_cast<f2*>(a.dst + k * ps + slot[q]));
           }
       }
+    };
+    if constexpr (FULL) {          // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
+#pragma unroll
+      for (int j = 2; j <= K; ++j) in_lds_substep(j);
+    } else {
+#pragma unroll 1
+      for (int j = 2; j <= ksteps; ++j) in_lds_substep(j);
     }
   }
 
