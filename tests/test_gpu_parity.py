@@ -23,6 +23,13 @@ SMALL = ["tiny_8x3", "open_64x48", "rand_64x48", "walls_40x24", "dense_32x32", "
 AV_EXACT_RTOL = 1e-6
 
 
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def sha256(path):
     h = hashlib.sha256()
     with open(path, "rb") as fh:
@@ -422,7 +429,7 @@ def test_python_cli_under_torchrun_world_of_one(lbm, digests, tmp_path):
     name = "128x256_t2000"
     ppath, opath = deck_paths(name, digests)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = [l for l in r.stdout.splitlines() if l.strip()]
@@ -463,7 +470,7 @@ def test_several_ranks_share_the_gpu_over_gloo(lbm, digests, tmp_path, ranks, na
     ppath, opath = deck_paths(name, digests)
     env = dict(os.environ, LBM_FORCE_DEVICE="0", LBM_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(29550 + ranks), os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = [l for l in r.stdout.splitlines() if l.strip()]
