@@ -221,12 +221,15 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
       const int cell = sr * nx + gx;
       const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
       f2 out[9];
-      const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
+      // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
+      // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
+      const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
+                         x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned;
       acc[0] += finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
-      } else {
+      } else if (owned) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], reinterpret_cast<f2*>(a.dst + k * ps + cell));
       }
@@ -265,13 +268,14 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
           if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
           const int cell = sr * nx + gx;
           const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
-          const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY;
+          const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
+                             x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned;
           const double term = finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
                                           owned, outs[q]);
 #pragma unroll
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;
-          slot[q] = last ? cell : c;
+          slot[q] = last ? (owned ? cell : -1) : c;
         }
       }
       if (!last) {

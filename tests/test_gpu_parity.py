@@ -555,3 +555,23 @@ def test_k_step_mode_with_several_partitions(lbm, oracle, digests, monkeypatch, 
     assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
     for part in parts:
         part.close()
+
+
+@pytest.mark.parametrize("K", [2, 3, 4])
+@pytest.mark.parametrize("nx,ny", [(128, 32), (130, 34), (200, 150), (1000, 1000), (1026, 258), (190, 47)])
+def test_k_steps_kernel_on_grids_that_tiles_do_not_divide(lbm, oracle, monkeypatch, nx, ny, K):
+    """Even nx >= 128, ny >= 32: the last tile column / row of lbm_multi_kernel sticks out of the grid;
+    the overhanging cells are periodic images that are computed but neither stored nor summed."""
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", str(K))
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    steps = 40 if nx * ny > 500000 else 95
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 3 + ny, False)
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"] == f"lbm_multi_kernel<{K}>"
+    av = np.concatenate([s.run(steps), s.run(2)])
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps + 2, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
