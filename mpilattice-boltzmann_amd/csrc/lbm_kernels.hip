@@ -393,19 +393,10 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   HIP_TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY_C(hipEventCreate(&c->ev_begin));
   HIP_TRY_C(hipEventCreate(&c->ev_end));
-  if (tune_env("LBM_TUNE_ONEALLOC", 0)) {
-    // both grids in one allocation: fixed relative placement (tuning experiment)
-    const size_t gap = 64 * static_cast<size_t>(tune_env("LBM_TUNE_GRIDGAP", 0));
-    HIP_TRY_C(hipMalloc(&c->grid_alloc[0], sizeof(float) * (2 * c->grid_floats + gap)));
-    HIP_TRY_C(hipMemsetAsync(c->grid_alloc[0], 0, sizeof(float) * (2 * c->grid_floats + gap), c->stream));
-    c->grid[0] = c->grid_alloc[0] + 64;
-    c->grid[1] = c->grid_alloc[0] + c->grid_floats + gap + 64;
-  } else {
-    for (int g = 0; g < 2; ++g) {
-      HIP_TRY_C(hipMalloc(&c->grid_alloc[g], sizeof(float) * c->grid_floats));
-      HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
-      c->grid[g] = c->grid_alloc[g] + 64;
-    }
+  for (int g = 0; g < 2; ++g) {
+    HIP_TRY_C(hipMalloc(&c->grid_alloc[g], sizeof(float) * c->grid_floats));
+    HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
+    c->grid[g] = c->grid_alloc[g] + 64;
   }
   // obstacle bitfield
   const size_t mwords = (c->ncells_storage + 31) / 32 + 4;
