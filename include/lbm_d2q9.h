@@ -84,7 +84,7 @@ int lbm_destroy(lbm_ctx* ctx);
  * Scatterv, d2q9-bgk.c:917-970).  Knowing the rows around the partition lets a row-partitioned
  * context run in K-step mode: K ghost rows on each side of the owned rows, refreshed by the
  * neighbours every K steps, all steps done K at a time by lbm_multi_kernel (lbm_macro_* below).
- * Chosen when nx % 64 == 0, ny_local % 16 == 0, ny_local >= 32 and LBM_FLAG_ONE_STEP is not set;
+ * Chosen when ny_local >= 32, nx is a multiple of 64 or an even number >= 128, and LBM_FLAG_ONE_STEP is not set;
  * lbm_macro_steps() tells.  Self-contained domains (ny_local == ny) are unaffected. */
 int lbm_create_global(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacles_all,
                       int y0, int ny_local, int device, unsigned flags);

@@ -194,6 +194,9 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
       int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;            // periodic (:527-529)
       int sr = sy0 + fy - EY;
       int ys = sr - 1, yn = sr + 1;
+      // row partition whose rows the tile height does not divide: the last tile row sticks out past the
+      // ghost rows; those cells lie outside every owned cell's dependency cone and are skipped
+      if (!a.y_periodic && yn >= rows_storage) continue;
       if (a.y_periodic) {                                                                 // periodic (:245-247)
         if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
         ys = (sr == 0) ? rows_storage - 1 : sr - 1;
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
       for (int q = 0; q < G::passes; ++q) {
         const int i = tid + q * kMLanes;
         slot[q] = -1;
-        if (i < np) {
+        if (i < np && (a.y_periodic || sy0 + (EY - ey + i / wp) - EY < rows_storage)) {   // (same skip as in sub-step 1)
           const int ry = i / wp, rp = i - ry * wp;
           const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;
           const int c = fy * W + fx;

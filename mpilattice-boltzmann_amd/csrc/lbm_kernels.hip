@@ -353,8 +353,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->ncells = static_cast<size_t>(p->nx) * ny_local;
   // K-step mode of a row-partitioned run: K ghost rows on each side of the owned rows, refreshed by the
   // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
-  if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && p->nx % kMTX == 0 && ny_local % kMTY == 0 &&
-      ny_local >= 2 * kMTY) {
+  if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && ny_local >= 2 * kMTY &&
+      (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX))) {
     // measured on a 1-rank ring with the packed exchange, us/step for K = 2 / 3 / 4 (one-step loop):
     //   8192x4096 rows 247 / 255 / 268   8192x1024 rows 72.5 / 70.1 / 72.3 (116)   1024x512 rows 25.7 / 17.6 / 15.0
     //   1024x128 rows 25.0 / 18.4 / 14.4 (37)
@@ -451,8 +451,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
-    c->multi_tiles_x = p->nx / kMTX;
-    c->multi_tiles = c->multi_tiles_x * (ny_local / kMTY);
+    c->multi_tiles_x = (p->nx + kMTX - 1) / kMTX;
+    c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
   } else if (!c->tile_kernel && self_periodic &&
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
@@ -825,13 +825,27 @@ int lbm_macro_prepare(lbm_ctx* c, int n_steps, void* stream)
 
 static int macro_k(const lbm_ctx* c) { return std::min(c->multi_K, c->run_steps - c->run_done); }
 
+// Tile rows of a K-step partition: row 0 and the top `top_edge_rows` rows read ghost rows (edge launch,
+// after the exchange); the `interior_rows` rows between them do not.  The top edge is two tile rows
+// when the last one holds fewer than K owned rows (the ring of the row below then reaches the ghosts).
+struct MacroRows { int interior_rows, top_edge_rows; };
+static MacroRows macro_rows(const lbm_ctx* c)
+{
+  const int nty = (c->nyl + kMTY - 1) / kMTY;
+  const int last_rows = c->nyl - (nty - 1) * kMTY;
+  int top = last_rows < c->multi_K ? 2 : 1;
+  top = std::min(top, nty - 1);
+  return {nty - 1 - top, top};
+}
+
 int lbm_macro_interior(lbm_ctx* c, void* stream)
 {
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_interior: not a K-step context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_interior: no steps left; call lbm_macro_prepare"); return 1; }
-  const int k = macro_k(c), nty = c->nyl / kMTY;
-  if (nty >= 3) {   // tile rows whose K-ring stays inside the owned rows
-    launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * (nty - 2), 0, 0, /*fold=*/true,
+  const int k = macro_k(c);
+  const MacroRows r = macro_rows(c);
+  if (r.interior_rows > 0) {   // tile rows whose K-ring stays inside the owned rows
+    launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * r.interior_rows, 0, 0, /*fold=*/true,
                  pick_stream(c, stream));
     HIP_TRY(hipGetLastError());
     c->n_prev = 0;   // folded by this launch's block 0
@@ -843,9 +857,10 @@ int lbm_macro_edge(lbm_ctx* c, void* stream)
 {
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_edge: not a K-step context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_edge: no steps left; call lbm_macro_prepare"); return 1; }
-  const int k = macro_k(c), nty = c->nyl / kMTY;
-  launch_multi(c, k, c->run_done + k < c->run_steps, 0, c->multi_tiles_x, (nty - 1) * c->multi_tiles_x, c->multi_tiles_x,
-               /*fold=*/c->n_prev > 0, pick_stream(c, stream));
+  const int k = macro_k(c);
+  const MacroRows r = macro_rows(c);
+  launch_multi(c, k, c->run_done + k < c->run_steps, 0, c->multi_tiles_x, (1 + r.interior_rows) * c->multi_tiles_x,
+               r.top_edge_rows * c->multi_tiles_x, /*fold=*/c->n_prev > 0, pick_stream(c, stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -575,3 +575,58 @@ def test_k_steps_kernel_on_grids_that_tiles_do_not_divide(lbm, oracle, monkeypat
     ref_cells, _, ref_exact = oracle.run(p, obst, steps + 2, nthreads=4)
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("nx,ny,size,K", [(256, 200, 3, 2), (256, 200, 3, 3), (130, 100, 2, 4), (1000, 1000, 8, 3),
+                                          (192, 99, 2, 3), (128, 260, 8, 4), (512, 70, 2, 2), (256, 131, 4, 3)])
+def test_k_step_partitions_with_rows_the_tile_does_not_divide(lbm, oracle, monkeypatch, nx, ny, size, K):
+    """Row partitions with arbitrary row counts (the reference's decomposition gives 125 rows per rank
+    for a 1000-row grid on 8 ranks): the last tile row sticks out past the ghost rows and the top edge
+    launch covers two tile rows when the last one is thinner than K."""
+    import torch
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    steps = 31
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 5 + ny, False)
+    free = lbm.count_free_cells(obst)
+    ny_local, displs = lbm.decompose(ny, size)
+    parts = [lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r], obstacles_global=obst) for r in range(size)]
+    assert all(part.macro_steps == K for part in parts), [part.macro_steps for part in parts]
+    tstream = torch.cuda.Stream(torch.device("cuda", 0))
+    st = tstream.cuda_stream
+    with torch.cuda.stream(tstream):
+        for part in parts:
+            part.macro_prepare(steps, st)
+        done = 0
+        while done < steps:
+            for r, part in enumerate(parts):
+                part.macro_receive_from(parts[(r - 1) % size], lbm.NORTH, st)
+                part.macro_receive_from(parts[(r + 1) % size], lbm.SOUTH, st)
+            for part in parts:
+                part.macro_interior(st)
+                part.macro_edge(st)
+            for part in parts:
+                part.macro_finish(st)
+            done += K
+        sums = sum(part.step_collect(steps, st) for part in parts)
+    tstream.synchronize()
+    cells = np.concatenate([part.get_cells() for part in parts], axis=0)
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    av = sums * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+    for part in parts:
+        part.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(200, 150), (130, 37), (1000, 125)])
+def test_k_step_ring_of_one_with_odd_rows(lbm, oracle, nx, ny):
+    p = lbm.Params(nx, ny, 40, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx + ny, False)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    assert sim.partition.macro_steps > 0
+    av = sim.run(40)
+    ref_cells, _, ref_exact = oracle.run(p, obst, 40, nthreads=4)
+    assert np.array_equal(bits(sim.local_cells()), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    sim.close()
