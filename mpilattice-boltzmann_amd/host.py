@@ -439,16 +439,45 @@ class Simulation:
                 raise ValueError("a forced-halo run outside torch.distributed needs exchange='rccl'")
             self._ring = RcclRing(self.partition, rank=0, size=1)
         elif self._partitioned and exchange == "rccl":
-            self._ring = RcclRing(self.partition, group)
+            self._ring = self._ring_or_none(group)
+            if self._ring is None:      # every rank agreed: the native loop is unavailable, use the torch loop
+                self.partition.close()
+                self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device,
+                                           flags | _capi.FLAG_ONE_STEP, obstacles_global=obstacles)
+                self._setup_torch_loop(device)
         elif self._partitioned:
-            import torch
-            self._torch_device = torch.device("cuda", device)
-            # one explicit stream carries the step kernels; RCCL orders its own stream against it
-            # at batch_isend_irecv() (start) and at wait(), so the exchange overlaps step_interior
-            self._stream = torch.cuda.Stream(self._torch_device)
-            with torch.cuda.stream(self._stream):
-                self.partition.bind_halo_tensors(self._torch_device)
-            self._stream.synchronize()
+            self._setup_torch_loop(device)
+
+    def _ring_or_none(self, group) -> Optional[RcclRing]:
+        """RcclRing, or None on EVERY rank if liblbm_d2q9_rccl.so or its communicator failed on any."""
+        import torch
+        import torch.distributed as dist
+        ring, err = None, None
+        try:
+            ring = RcclRing(self.partition, group)
+        except (LbmError, RuntimeError, OSError) as e:       # missing library, RCCL error
+            err = e
+        ok = torch.tensor([0 if ring is None else 1], dtype=torch.int32,
+                          device="cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", self.device))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return ring
+        if ring is not None:
+            ring.close()
+        if self.rank == 0:
+            import warnings
+            warnings.warn(f"native RCCL loop unavailable ({err}); falling back to the torch.distributed loop")
+        return None
+
+    def _setup_torch_loop(self, device: int) -> None:
+        import torch
+        self._torch_device = torch.device("cuda", device)
+        # one explicit stream carries the step kernels; RCCL orders its own stream against it
+        # at batch_isend_irecv() (start) and at wait(), so the exchange overlaps step_interior
+        self._stream = torch.cuda.Stream(self._torch_device)
+        with torch.cuda.stream(self._stream):
+            self.partition.bind_halo_tensors(self._torch_device)
+        self._stream.synchronize()
 
     @classmethod
     def from_files(cls, paramfile: str, obstaclefile: str, **kw) -> "Simulation":

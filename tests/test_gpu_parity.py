@@ -630,3 +630,28 @@ def test_k_step_ring_of_one_with_odd_rows(lbm, oracle, nx, ny):
     assert np.array_equal(bits(sim.local_cells()), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
     sim.close()
+
+
+def test_fallback_to_the_torch_loop_when_the_native_loop_is_unavailable(lbm, oracle, digests, tmp_path, monkeypatch):
+    """If liblbm_d2q9_rccl.so cannot be used on any rank, every rank switches to the torch.distributed
+    loop (agreed by an all-reduce) instead of failing."""
+    import torch
+    import torch.distributed as dist
+    p, obst, free = load_case(lbm, digests, "rand_64x48")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    monkeypatch.setattr(lbm._capi, "LIB_RCCL_PATH", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(lbm._capi, "_lib_rccl", None)
+    try:
+        with pytest.warns(UserWarning, match="falling back"):
+            sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, distributed=True, exchange="rccl")
+        assert sim._ring is None and sim.partition.macro_steps == 0
+        av = sim.run(40)
+        cells = sim.gather_cells()
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 40)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
