@@ -1,7 +1,8 @@
-// lbm_kernels.hip — hand-written gfx950 (MI355X / CDNA4) kernels + device half of the C ABI
+// lbm_kernels.hip — the translation unit of liblbm_d2q9.so's device half: it includes the hand-written
+// gfx950 (MI355X / CDNA4) kernels (kernels/*.h) and implements the device entry points of the C ABI
 // (include/lbm_d2q9.h) for the D2Q9-BGK timestep path of ag14774/MPILattice-Boltzmann.
 //
-// What one launch of lbm_step_* does (reference lines, relative to the reference tree):
+// What one lattice step does, whichever kernel performs it (reference lines, relative to its tree):
 //   pull-stream            d2q9-bgk.c:526-538      9 populations from the 3x3 neighbourhood
 //   moments + equilibrium  d2q9-bgk.c:546-646
 //   BGK relaxation         d2q9-bgk.c:658-666      fluid cells
@@ -9,18 +10,20 @@
 //   sum |u|                d2q9-bgk.c:667,684      -> per-block partial, double
 //   accelerate_flow        d2q9-bgk.c:442-478      fused as an EPILOGUE on global row ny-2: the row is
 //                                                  written already accelerated for the next step
-//   av_vels[tt-1]          d2q9-bgk.c:367          block 0 folds the previous launch's partials
+//   av_vels[tt-1]          d2q9-bgk.c:367          block 0 of the next launch folds the partials
 //
-// Kernels in this file (all produce the same bits; lbm_run / the partitioned loop pick by grid size):
-//   lbm_step_kernel / _narrow / _lds   one step per launch (4 cells, 1 cell per lane; LDS-staged variant)
-//   lbm_multi_kernel<K>                K steps per pass over HBM, 64x16 tiles, intermediate states in LDS
-//   lbm_tile_kernel<T,H>               up to H steps per launch for the launch-latency-bound small grids
+// Kernels (all produce the same bits; lbm_run / the partitioned loops pick by grid):
+//   kernels/multi.h  lbm_multi_kernel<K>                K steps per pass over HBM, 64x16 tiles, intermediate
+//                                                       states in LDS — large grids and K-step row partitions
+//   kernels/tile.h   lbm_tile_kernel<T,H>               up to H steps per launch, launch-latency-bound small grids
+//   kernels/step.h   lbm_step_kernel / _narrow / _lds   one step per launch (4 cells or 1 cell per lane; the
+//                                                       LDS-staged variant) — everything else
+//   kernels/aux.h    fold, accelerate pre-pass, initial state, AoS<->SoA, halo pack/unpack, av_velocity
 //
-// Layout in HBM: struct-of-arrays, 9 planes of ny_local*nx floats (plane stride padded, see
-// plane_stride_floats()), two grids (source / destination, swapped per step like :376-378), the
-// obstacle map as a bitfield (1 bit per cell).  Every population value is consumed by exactly one
-// cell per step, so the kernel is a pure stream: 9 x 16-byte loads + 9 x 16-byte stores per lane
-// (4 cells per lane), no MFMA, bounded by HBM bandwidth.
+// Layout in HBM: struct-of-arrays, 9 planes of rows*nx floats (plane stride padded, see
+// plane_stride_floats()), two grids (source / destination, swapped per launch like :376-378), the
+// obstacle map as a bitfield (1 bit per cell); K-step row partitions carry K ghost rows per side.
+// No MFMA anywhere: nothing on this path is a contraction.
 //
 // Arithmetic is written in the reference's operation order and this file is compiled with
 // -ffp-contract=off, so the post-step populations are BIT-IDENTICAL to the reference's
