@@ -848,8 +848,8 @@ int lbm_macro_interior(lbm_ctx* c, void* stream)
   const int k = macro_k(c);
   const MacroRows r = macro_rows(c);
   if (r.interior_rows > 0) {   // tile rows whose K-ring stays inside the owned rows
-    launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * r.interior_rows, 0, 0, /*fold=*/true,
-                 pick_stream(c, stream));
+    launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * r.interior_rows, 0, 0,
+                 /*fold=*/c->n_prev > 0, pick_stream(c, stream));
     HIP_TRY(hipGetLastError());
     c->n_prev = 0;   // folded by this launch's block 0
   }
@@ -862,9 +862,11 @@ int lbm_macro_edge(lbm_ctx* c, void* stream)
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_edge: no steps left; call lbm_macro_prepare"); return 1; }
   const int k = macro_k(c);
   const MacroRows r = macro_rows(c);
+  // whichever of the two launches of a macro-step comes first folds the previous macro-step's sums
   launch_multi(c, k, c->run_done + k < c->run_steps, 0, c->multi_tiles_x, (1 + r.interior_rows) * c->multi_tiles_x,
                r.top_edge_rows * c->multi_tiles_x, /*fold=*/c->n_prev > 0, pick_stream(c, stream));
   HIP_TRY(hipGetLastError());
+  c->n_prev = 0;
   return 0;
 }
 
