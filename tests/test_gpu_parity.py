@@ -655,3 +655,20 @@ def test_fallback_to_the_torch_loop_when_the_native_loop_is_unavailable(lbm, ora
     ref_cells, _, ref_exact = oracle.run(p, obst, 40)
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+def test_full_1024_deck_as_a_k_step_ring_matches_the_reference_file(lbm, digests, tmp_path):
+    """All 20 000 steps of the shipped 1024x1024 deck through the row-partitioned code path (K-step
+    mode, native RCCL loop, 1-rank ring): final_state.dat must still be the reference binary's file."""
+    name = "1024x1024"
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    assert sim.partition.macro_steps > 0
+    av = sim.run()
+    cells = sim.local_cells()
+    assert "Reynolds number:\t\t%.12E" % sim.reynolds(cells) == digests[name]["reynolds_line"]
+    sim.write_values(av, str(tmp_path), cells)
+    sim.close()
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    steps = np.asarray(digests[name]["av_sample_steps"])
+    assert np.allclose(av[steps], digests[name]["av_sample_values"], rtol=4e-3)
