@@ -204,7 +204,9 @@ def main() -> None:
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath))
-            if t.get("workload") == f"{nx}x{ny}" and world == 1 and not args.ring:
+            # PMC passes are separate runs (rocprofv3 --pmc), so the figure is read from the committed
+            # summary; it is only quoted when it was measured for this workload AND this kernel
+            if t.get("workload") == f"{nx}x{ny}" and t.get("kernel") == desc["kernel"] and world == 1 and not args.ring:
                 traffic = t.get("hbm_bytes_per_launch")
         out = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
