@@ -75,7 +75,8 @@ int lbm_decompose(int ny, int size, int* ny_local, int* displs);
  * [y0, y0+ny_local) of the global grid, on HIP device `device`.  obstacles_rows = this partition's
  * ny_local*nx ints.  free_cells is the GLOBAL count.  ny_local == p->ny makes a self-contained
  * periodic domain (the reference's 1-rank run, where top == bottom == self, :245-247).
- * Requires nx % 4 == 0, ny_local >= 1 (>= 3 on the partition holding global row ny-2). */
+ * Any nx >= 1, ny >= 3, ny_local >= 1 (>= 3 on the partition holding global row ny-2); the kernel
+ * form is chosen from the shape (nx % 4 != 0 runs the one-cell-per-lane form). */
 int lbm_create(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacles_rows,
                int y0, int ny_local, int device, unsigned flags);
 int lbm_destroy(lbm_ctx* ctx);
