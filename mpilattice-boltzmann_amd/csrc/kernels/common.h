@@ -73,47 +73,99 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 d
 // fold's latency (a dependent load + two barriers) is off the critical path of the tiny grids.
 __device__ __forceinline__ void fold_previous(const StepArgs& a, double* red);
 
-// One cell: moments, equilibrium, relaxation in the reference's operation order (d2q9-bgk.c:546-666).
-// t[] = streamed-in populations, o[] = relaxed populations; returns sqrt(m^2)/rho in double (:667).
-__device__ __forceinline__ void relax_cell_core(const float (&t)[9], float omega, float (&o)[9], float& msq_out, float& rinv_out);
+// sqrt((double)x) for a float x (d2q9-bgk.c:667 promotes u_sq to double).  Same Newton sequence on
+// v_rsq_f64 that hipcc emits for sqrt(double), minus its 2^256 rescaling of arguments below 2^-767,
+// which a converted float never is: bit-identical results, a quarter fewer instructions.
+__device__ __forceinline__ double sqrt_of_float(float xf)
+{
+  const double x = static_cast<double>(xf);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;     // +-0 and +inf map to themselves
+}
 
+// One cell (T = float) or an x-pair of cells (T = f2, packed v_pk_*_f32): moments, equilibrium and
+// relaxation (d2q9-bgk.c:546-666).  Every value is produced by the reference's own sequence of
+// roundings; two things differ in form only:
+//   - opposite directions share work.  u[3] = -u[1], u[4] = -u[2], u[7] = -u[5], u[6] = -u[8] exactly
+//     (:596-603; a sum and its mirror round alike), so "u*ic_sq" of one is the negation of the other's and
+//     "u*u*ic_sq", "- u_sq", "* 0.5f*densinv*ic_sq" are equal: computed once for the pair of
+//     directions, with "rho - a" standing for "rho + (-a)" (18 of 113 operations less);
+//   - the independent chains are written interleaved.  gfx950 needs a wait state between a packed
+//     instruction and a consumer of its result, which hipcc fills with s_nop (4 cycles, as much as
+//     the instruction itself) when the next instruction in program order is that consumer.
+// msq = m^2 (un-normalised momentum squared), rinv = 1/rho.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ float splat_as(float, float v) { return v; }
+__device__ __forceinline__ f2 splat_as(f2, float v) { return f2{v, v}; }
+__device__ __forceinline__ float recip_exact(float x) { return 1.0f / x; }                  // correctly rounded division (:561)
+__device__ __forceinline__ f2 recip_exact(f2 x) { f2 r; r.x = 1.0f / x.x; r.y = 1.0f / x.y; return r; }
+
+template <typename T>
+__device__ __forceinline__ void relax_core(const T (&t)[9], float omega, T (&o)[9], T& msq_out, T& rinv_out)
+{
+  const T csq_inv = splat_as(T{}, 3.0f);                                                     // :497
+  const T w0 = splat_as(T{}, 4.0f / 9.0f), w1 = splat_as(T{}, 1.0f / 9.0f), w2 = splat_as(T{}, 1.0f / 36.0f);   // :499-501
+  const T om = splat_as(T{}, omega), half = splat_as(T{}, 0.5f);
+  T rho = t[0] + t[1];                                           // :546-554, :570-574, :576-580 side by side
+  T mx = t[1] + t[5];
+  T my = t[2] + t[5];
+  rho += t[2]; mx += t[8]; my += t[6];
+  rho += t[3]; mx -= t[3]; my -= t[4];
+  rho += t[4]; mx -= t[6]; my -= t[7];
+  rho += t[5]; mx -= t[7]; my -= t[8];
+  rho += t[6];
+  const T mxx = mx * mx, myy = my * my;
+  const T e5 = mx + my, e8 = mx - my;                            // :600,603 (u[7] = -e5, u[6] = -e8)
+  rho += t[7];
+  const T msq = mxx + myy;                                       // :589
+  T a[4] = {mx * csq_inv, my * csq_inv, e5 * csq_inv, e8 * csq_inv};        // :610-617 for k = 1, 2, 5, 8
+  rho += t[8];
+  const T rinv = recip_exact(rho);                               // :561
+  T d[4] = {a[0] * mx, a[1] * my, a[2] * e5, a[3] * e8};         // :624-631
+  const T h = half * rinv * csq_inv;                             // "0.5f*densinv*ic_sq" of :638-646
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = d[i] - msq;
+  const T hm = h * msq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = h * d[i];
+  T s[9];                                                        // :638-646
+  s[0] = rho - hm;
+  s[1] = rho + a[0]; s[3] = rho - a[0];
+  s[2] = rho + a[1]; s[4] = rho - a[1];
+  s[5] = rho + a[2]; s[7] = rho - a[2];
+  s[8] = rho + a[3]; s[6] = rho - a[3];
+  s[1] += d[0]; s[3] += d[0]; s[2] += d[1]; s[4] += d[1];
+  s[5] += d[2]; s[7] += d[2]; s[8] += d[3]; s[6] += d[3];
+  s[0] = w0 * s[0];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) s[k] = ((k < 5) ? w1 : w2) * s[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = s[k] - t[k];                // :658-666
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = om * s[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = t[k] + s[k];
+  msq_out = msq;
+  rinv_out = rinv;
+}
+
+// One cell; returns sqrt(m^2)/rho in double (:667).
 __device__ __forceinline__ double relax_cell(const float (&t)[9], float omega, float (&o)[9])
 {
   float msq, rinv;
-  relax_cell_core(t, omega, o, msq, rinv);
-  return sqrt(static_cast<double>(msq)) * static_cast<double>(rinv);   // :667
-}
-
-// The same without the sum|u| term: msq = m^2 (un-normalised momentum squared), rinv = 1/rho.
-__device__ __forceinline__ void relax_cell_core(const float (&t)[9], float omega, float (&o)[9], float& msq_out, float& rinv_out)
-{
-  const float csq_inv = 3.0f;                                   // :497
-  const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;   // :499-501
-  float rho = t[0];                                             // :546-554
-  rho += t[1]; rho += t[2]; rho += t[3]; rho += t[4];
-  rho += t[5]; rho += t[6]; rho += t[7]; rho += t[8];
-  const float rinv = 1.0f / rho;                                // :561
-  float mx = t[1] + t[5];                                       // :570-574
-  mx += t[8]; mx -= t[3]; mx -= t[6]; mx -= t[7];
-  float my = t[2] + t[5];                                       // :576-580
-  my += t[6]; my -= t[4]; my -= t[7]; my -= t[8];
-  const float msq = mx * mx + my * my;                          // :589
-  float e[9];
-  e[1] = mx;       e[2] = my;        e[3] = -mx;       e[4] = -my;        // :596-599
-  e[5] = mx + my;  e[6] = -mx + my;  e[7] = -mx - my;  e[8] = mx - my;    // :600-603
-  const float h = 0.5f * rinv * csq_inv;                        // "0.5f*densinv*ic_sq" of :638-646
-  const float q0 = w0 * (rho - h * msq);                        // :638
-  o[0] = t[0] + omega * (q0 - t[0]);                            // :658
-#pragma unroll
-  for (int k = 1; k < 9; ++k) {
-    const float a = e[k] * csq_inv;                             // :610-617
-    const float b = a * e[k];                                   // :624-631
-    const float wk = (k < 5) ? w1 : w2;
-    const float q = wk * (rho + a + h * (b - msq));             // :639-646
-    o[k] = t[k] + omega * (q - t[k]);                           // :659-666
-  }
-  msq_out = msq;
-  rinv_out = rinv;
+  relax_core<float>(t, omega, o, msq, rinv);
+  return sqrt_of_float(msq) * static_cast<double>(rinv);   // :667
 }
 
 // Row bases of the three source rows of destination row y, per population (d2q9-bgk.c:511-512,
@@ -149,8 +201,6 @@ __device__ __forceinline__ RowPtrs source_rows(const StepArgs& a, int y)
 }
 
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ void bounce_or_relax(const float (&t)[9], const float (&o)[9], bool blocked, float (&out)[9])
 {

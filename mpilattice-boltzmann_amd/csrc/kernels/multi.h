@@ -33,14 +33,14 @@ struct MultiGeom {
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
   static constexpr int W = kMTX + 2 * EX, H = kMTY + 2 * EY;        // LDS frame
   static constexpr int cells = W * H;
-  static constexpr int pairs2 = K >= 2 ? ((kMTX + 4 * (K - 2)) / 2) * (kMTY + 2 * (K - 2)) : 0;   // largest in-LDS region
-  static constexpr int passes = (pairs2 + kMLanes - 1) / kMLanes;
   static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64);
 };
 
 struct MultiArgs {
   const float* src;
   float* dst;
+  const float* srck[9];        // src + k*ps, dst + k*ps: plane bases as kernel arguments, so that they are scalar
+  float* dstk[9];              // loads at the point of use and never 64-bit vector arithmetic
   const uint32_t* mask;        // bit per STORAGE cell (ghost rows included)
   size_t ps;
   int nx;
@@ -63,72 +63,60 @@ struct MultiArgs {
   int* counter;
 };
 
+// base + 32-bit byte offset: the form hipcc turns into "global_load/store v_off, s[base]" (needs < 4 GiB per grid)
+template <typename V, typename B>
+__device__ __forceinline__ auto& at_byte(B* base, uint32_t byte_off)
+{
+  using P = std::conditional_t<std::is_const_v<B>, const V, V>;
+  using C = std::conditional_t<std::is_const_v<B>, const char, char>;
+  return *reinterpret_cast<P*>(reinterpret_cast<C*>(base) + byte_off);
+}
+
 // Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
 // p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
 // Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
 // double-precision sqrt is a tenth of the cell's instructions).
-__device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool accel, float w1, float w2,
+// tile_accel is block-uniform: false for the tiles whose frame does not meet row ny-2, which then skip
+// the accelerate_flow code instead of predicating it away in every pair.
+__device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
                                               bool want_term, f2 (&out)[9])
 {
-  // relax_cell_core on both cells at once: every line is the scalar line with f2 operands, so each
-  // component sees exactly the reference's operation order (d2q9-bgk.c:546-666) and hipcc emits
-  // packed v_pk_add_f32 / v_pk_mul_f32 for all of it.
-  const f2 csq_inv = {3.0f, 3.0f};                                     // :497
-  const float w0 = 4.0f / 9.0f, wa = 1.0f / 9.0f, wd = 1.0f / 36.0f;   // :499-501
-  f2 rho = t[0];                                                       // :546-554
-  rho += t[1]; rho += t[2]; rho += t[3]; rho += t[4];
-  rho += t[5]; rho += t[6]; rho += t[7]; rho += t[8];
-  f2 rinv;                                                             // :561 (correctly rounded division per cell)
-  rinv.x = 1.0f / rho.x; rinv.y = 1.0f / rho.y;
-  f2 mx = t[1] + t[5];                                                 // :570-574
-  mx += t[8]; mx -= t[3]; mx -= t[6]; mx -= t[7];
-  f2 my = t[2] + t[5];                                                 // :576-580
-  my += t[6]; my -= t[4]; my -= t[7]; my -= t[8];
-  const f2 msq = mx * mx + my * my;                                    // :589
-  f2 e[9];
-  e[1] = mx;        e[2] = my;         e[3] = -mx;        e[4] = -my;          // :596-599
-  e[5] = mx + my;   e[6] = -mx + my;   e[7] = -mx - my;   e[8] = mx - my;      // :600-603
-  const f2 half = {0.5f, 0.5f};
-  const f2 h = half * rinv * csq_inv;                                  // "0.5f*densinv*ic_sq" of :638-646
-  const f2 om = {omega, omega};
-  f2 o[9];
-  {
-    const f2 wv = {w0, w0};
-    const f2 q0 = wv * (rho - h * msq);                                // :638
-    o[0] = t[0] + om * (q0 - t[0]);                                    // :658
-  }
-#pragma unroll
-  for (int k = 1; k < 9; ++k) {
-    const f2 a = e[k] * csq_inv;                                       // :610-617
-    const f2 b = a * e[k];                                             // :624-631
-    const float wk = (k < 5) ? wa : wd;
-    const f2 wv = {wk, wk};
-    const f2 q = wv * (rho + a + h * (b - msq));                       // :639-646
-    o[k] = t[k] + om * (q - t[k]);                                     // :659-666
-  }
+  f2 o[9], msq, rinv;
+  relax_core<f2>(t, omega, o, msq, rinv);                               // :546-666 on both cells at once (v_pk_*_f32)
   // bounce-back select (d2q9-bgk.c:687-695) and the next step's accelerate_flow (:457-469), per cell
   static constexpr int opp[9] = {0, 3, 4, 1, 2, 7, 8, 5, 6};
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const bool blocked = (mbits >> j) & 1u;
-    float r[9];
+  for (int k = 0; k < 9; ++k) out[k] = o[k];
+  if (__builtin_amdgcn_ballot_w64(mbits != 0u) != 0ull) {          // wave-uniform: most waves hold no obstacle
 #pragma unroll
-    for (int k = 0; k < 9; ++k) r[k] = blocked ? t[opp[k]][j] : o[k][j];
-    if (accel && !blocked) accelerate_cell(r, w1, w2);
+    for (int j = 0; j < 2; ++j) {
+      const bool blocked = (mbits >> j) & 1u;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) out[k][j] = r[k];
+      for (int k = 0; k < 9; ++k) out[k][j] = blocked ? t[opp[k]][j] : o[k][j];
+    }
+  }
+  if (tile_accel) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float r[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) r[k] = out[k][j];
+      if (accel && !((mbits >> j) & 1u)) accelerate_cell(r, w1, w2);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) out[k][j] = r[k];
+    }
   }
   double term = 0.0;
   if (want_term) {
-    const double t0 = sqrt(static_cast<double>(msq.x)) * static_cast<double>(rinv.x);   // :667
-    const double t1 = sqrt(static_cast<double>(msq.y)) * static_cast<double>(rinv.y);
+    const double t0 = sqrt_of_float(msq.x) * static_cast<double>(rinv.x);   // :667
+    const double t1 = sqrt_of_float(msq.y) * static_cast<double>(rinv.y);
     term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
   }
   return term;
 }
 
 template <int K, bool FULL>   // FULL: this launch does exactly K steps (all region sizes are compile-time constants)
-__global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
+__global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K>;
   constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
@@ -175,6 +163,13 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
 #pragma unroll
   for (int i = 0; i < K; ++i) acc[i] = 0.0;
 
+  // does the LDS frame of this tile meet the global accelerate row ny-2 at all ?  (block-uniform)
+  bool tile_accel;
+  {
+    int d = (a.accel_row - (a.y0_global + ty * kMTY - EY)) % a.ny_global;     // frame row 0 is global row y0 + ty*16 - EY
+    if (d < 0) d += a.ny_global;
+    tile_accel = d < G::H || a.ny_global < G::H;
+  }
   // storage row -> does it hold the global accelerate row ny-2 ?
   auto on_accel_row = [&](int sr) {
     int g = a.y0_global + sr - a.ghost;
@@ -202,60 +197,70 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
         ys = (sr == 0) ? rows_storage - 1 : sr - 1;
         yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
       }
-      const float* here = a.src + static_cast<size_t>(sr) * nx + gx;
-      const float* south = a.src + static_cast<size_t>(ys) * nx + gx;
-      const float* north = a.src + static_cast<size_t>(yn) * nx + gx;
+      // three 32-bit byte offsets per lane on block-uniform plane bases (scalar base + vector offset
+      // addressing: no 64-bit address arithmetic in the vector unit; the x -+ 1 shifts live in the bases)
+      const int cell = sr * nx + gx;
+      const uint32_t o_here = 4u * static_cast<uint32_t>(cell);
+      const uint32_t o_south = 4u * static_cast<uint32_t>(ys * nx + gx);
+      const uint32_t o_north = 4u * static_cast<uint32_t>(yn * nx + gx);
       f2 p[9];
-      p[0] = *reinterpret_cast<const f2*>(here);                                           // :530
-      p[2] = *reinterpret_cast<const f2*>(south + 2 * ps);                                 // :532
-      p[4] = *reinterpret_cast<const f2*>(north + 4 * ps);                                 // :534
-      p[1] = *reinterpret_cast<const f2u*>(here + ps - 1);                                 // :531
-      p[5] = *reinterpret_cast<const f2u*>(south + 5 * ps - 1);                            // :535
-      p[8] = *reinterpret_cast<const f2u*>(north + 8 * ps - 1);                            // :538
-      p[3] = *reinterpret_cast<const f2u*>(here + 3 * ps + 1);                             // :533
-      p[6] = *reinterpret_cast<const f2u*>(south + 6 * ps + 1);                            // :536
-      p[7] = *reinterpret_cast<const f2u*>(north + 7 * ps + 1);                            // :537
+      p[0] = at_byte<f2>(a.srck[0], o_here);                                                   // :530
+      p[2] = at_byte<f2>(a.srck[2], o_south);                                         // :532
+      p[4] = at_byte<f2>(a.srck[4], o_north);                                         // :534
+      p[1] = at_byte<f2u>(a.srck[1] - 1, o_here);                                         // :531
+      p[5] = at_byte<f2u>(a.srck[5] - 1, o_south);                                    // :535
+      p[8] = at_byte<f2u>(a.srck[8] - 1, o_north);                                    // :538
+      p[3] = at_byte<f2u>(a.srck[3] + 1, o_here);                                     // :533
+      p[6] = at_byte<f2u>(a.srck[6] + 1, o_south);                                    // :536
+      p[7] = at_byte<f2u>(a.srck[7] + 1, o_north);                                    // :537
       if (gx == 0) {                          // x_w wraps to nx-1 (:529)
-        p[1].x = here[ps + nx - 1]; p[5].x = south[5 * ps + nx - 1]; p[8].x = north[8 * ps + nx - 1];
+        p[1].x = at_byte<float>(a.srck[1] + nx - 1, o_here); p[5].x = at_byte<float>(a.srck[5] + nx - 1, o_south);
+        p[8].x = at_byte<float>(a.srck[8] + nx - 1, o_north);
       }
       if (gx == nx - 2) {                     // x_e wraps to 0 (:527-528)
-        p[3].y = here[3 * ps + 2 - nx]; p[6].y = south[6 * ps + 2 - nx]; p[7].y = north[7 * ps + 2 - nx];
+        p[3].y = at_byte<float>(a.srck[3] + 2 - nx, o_here); p[6].y = at_byte<float>(a.srck[6] + 2 - nx, o_south);
+        p[7].y = at_byte<float>(a.srck[7] + 2 - nx, o_north);
       }
-      const int cell = sr * nx + gx;
-      const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+      const uint32_t mbits = (at_byte<uint32_t>(a.mask, 4u * (static_cast<uint32_t>(cell) >> 5)) >> (cell & 31)) & 3u;
       f2 out[9];
       // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
       // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
       const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
                          x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned;
-      acc[0] += finish_pair(p, mbits, a.omega, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
+      acc[0] += finish_pair(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
       } else if (owned) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], reinterpret_cast<f2*>(a.dst + k * ps + cell));
+        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], &at_byte<f2>(a.dstk[k], o_here));
       }
     }
   }
   if constexpr (K >= 2) {
     __syncthreads();
-    // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller
+    // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller.
+    // In place without holding a whole region in registers: sub-step j writes its row r where the
+    // frame it read kept row r-1 (the frame creeps down one storage row per sub-step), and a region
+    // of more than 512 pairs goes in passes of whole rows, bottom to top.  A pass reads, meets at a
+    // barrier, then writes; what it overwrites (old rows up to its last row - 1) no later pass reads.
     auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
       const int ey = ksteps - j, ex = 2 * ey;
-      const int wp = (kMTX + 2 * ex) / 2;
-      const int np = wp * (kMTY + 2 * ey);
+      const int wp = (kMTX + 2 * ex) / 2;                                // pairs per region row
+      const int rows = kMTY + 2 * ey;
+      const int rpp = kMLanes / wp;                                      // whole rows per pass
       const bool last = j == ksteps;
-      f2 outs[G::passes][9];
-      int slot[G::passes];
+      const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
+      const int ry = tid / wp, rp = tid - ry * wp;
+      const int fx = EX - ex + 2 * rp;
+      int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;
 #pragma unroll
-      for (int q = 0; q < G::passes; ++q) {
-        const int i = tid + q * kMLanes;
-        slot[q] = -1;
-        if (i < np && (a.y_periodic || sy0 + (EY - ey + i / wp) - EY < rows_storage)) {   // (same skip as in sub-step 1)
-          const int ry = i / wp, rp = i - ry * wp;
-          const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;
-          const int c = fy * W + fx;
+      for (int r0 = 0; r0 < rows; r0 += rpp) {
+        f2 outs[9];
+        int slot = -1;
+        const int fy = EY - ey + r0 + ry;
+        if (ry < rpp && r0 + ry < rows && (a.y_periodic || sy0 + fy - EY < rows_storage)) {   // (same skip as in sub-step 1)
+          const int c = fy * W + fx - rd;
           f2 p[9];
           p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + c);
           p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + c - W);
@@ -266,38 +271,31 @@ __global__ void __launch_bounds__(kMLanes) lbm_multi_kernel(const MultiArgs a)
           p[3] = f2{lds[3 * kCells + c + 1], lds[3 * kCells + c + 2]};
           p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
           p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
-          int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;
           int sr = sy0 + fy - EY;
           if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
           const int cell = sr * nx + gx;
-          const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+          const uint32_t mbits = (at_byte<uint32_t>(a.mask, 4u * (static_cast<uint32_t>(cell) >> 5)) >> (cell & 31)) & 3u;
           const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
                              x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned;
-          const double term = finish_pair(p, mbits, a.omega, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
-                                          owned, outs[q]);
+          const double term = finish_pair(p, mbits, a.omega, tile_accel, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
+                                          owned, outs);
 #pragma unroll
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;
-          slot[q] = last ? (owned ? cell : -1) : c;
+          slot = last ? (owned ? cell : -1) : fy * W + fx - wr;
+        }
+        if (!last) {
+          __syncthreads();                     // every lane of the pass has read its neighbours
+          if (slot >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + slot) = outs[k];
+          }
+        } else if (slot >= 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[k], &at_byte<f2>(a.dstk[k], 4u * static_cast<uint32_t>(slot)));
         }
       }
-      if (!last) {
-        __syncthreads();                       // every lane has read its neighbours
-#pragma unroll
-        for (int q = 0; q < G::passes; ++q)
-          if (slot[q] >= 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + slot[q]) = outs[q][k];
-          }
-        __syncthreads();
-      } else {
-#pragma unroll
-        for (int q = 0; q < G::passes; ++q)
-          if (slot[q] >= 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[q][k], reinterpret_cast<f2*>(a.dst + k * ps + slot[q]));
-          }
-      }
+      if (!last) __syncthreads();
     };
     if constexpr (FULL) {          // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
 #pragma unroll

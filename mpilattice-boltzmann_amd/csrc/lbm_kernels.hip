@@ -41,6 +41,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "lbm_d2q9.h"
@@ -227,6 +228,7 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
 {
   MultiArgs a{};
   a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
+  for (int k = 0; k < 9; ++k) { a.srck[k] = a.src + k * c->ps; a.dstk[k] = a.dst + k * c->ps; }
   a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx;
   a.rows_owned = c->nyl; a.ghost = c->ghost; a.y_periodic = c->self_periodic ? 1 : 0;
   a.y0_global = c->y0; a.ny_global = c->p.ny;
@@ -356,7 +358,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->ncells = static_cast<size_t>(p->nx) * ny_local;
   // K-step mode of a row-partitioned run: K ghost rows on each side of the owned rows, refreshed by the
   // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
-  if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && ny_local >= 2 * kMTY &&
+  // (the multi kernel addresses a plane with 32-bit byte offsets: < 2^30 storage cells)
+  const bool fits_u32 = static_cast<size_t>(p->nx) * (ny_local + 2 * kMaxMultiSteps) < (size_t(1) << 30);
+  if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && ny_local >= 2 * kMTY && fits_u32 &&
       (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX))) {
     // measured on a 1-rank ring with the packed exchange, us/step for K = 2 / 3 / 4 (one-step loop):
     //   8192x4096 rows 247 / 255 / 268   8192x1024 rows 72.5 / 70.1 / 72.3 (116)   1024x512 rows 25.7 / 17.6 / 15.0
@@ -457,7 +461,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tiles_x = (p->nx + kMTX - 1) / kMTX;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
-  } else if (!c->tile_kernel && self_periodic &&
+  } else if (!c->tile_kernel && self_periodic && fits_u32 &&
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
     // sticks out of the grid (periodic images: computed, not kept)
