@@ -33,7 +33,7 @@ struct MultiGeom {
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
   static constexpr int W = kMTX + 2 * EX, H = kMTY + 2 * EY;        // LDS frame
   static constexpr int cells = W * H;
-  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64);
+  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64) + (K >= 2 ? cells / 2 : 0);   // + a flag byte per x-pair
 };
 
 struct MultiArgs {
@@ -122,6 +122,9 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
   constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
+  // per x-pair of the frame, written by sub-step 1 and read by the in-LDS sub-steps (which then need no
+  // grid coordinates at all): bits 0-1 obstacle bits, 2 owned, 3 on the accelerate row, 4 computed
+  uint8_t* pair_flags = reinterpret_cast<uint8_t*>(red + K * kWaves);
   const int tid = threadIdx.x;
 
   if (blockIdx.x == 0) {
@@ -182,20 +185,30 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
     const int ey = ksteps - 1, ex = 2 * ey;
     const int wp = (kMTX + 2 * ex) / 2;                                 // pairs per region row
     const int np = wp * (kMTY + 2 * ey);
+    // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
+    // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
+    const bool inner = x0 - EX >= 2 && x0 + kMTX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + kMTY + EY + 1 <= rows_storage &&
+                       sy0 + kMTY <= a.ghost + a.rows_owned;
 #pragma unroll 1
     for (int i = tid; i < np; i += kMLanes) {
       const int ry = i / wp, rp = i - ry * wp;
       const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
-      int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;            // periodic (:527-529)
+      int gx = x0 + fx - EX;
       int sr = sy0 + fy - EY;
       int ys = sr - 1, yn = sr + 1;
-      // row partition whose rows the tile height does not divide: the last tile row sticks out past the
-      // ghost rows; those cells lie outside every owned cell's dependency cone and are skipped
-      if (!a.y_periodic && yn >= rows_storage) continue;
-      if (a.y_periodic) {                                                                 // periodic (:245-247)
-        if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
-        ys = (sr == 0) ? rows_storage - 1 : sr - 1;
-        yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
+      if (!inner) {
+        if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;                                // periodic (:527-529)
+        // row partition whose rows the tile height does not divide: the last tile row sticks out past the
+        // ghost rows; those cells lie outside every owned cell's dependency cone and are skipped
+        if (!a.y_periodic && yn >= rows_storage) {
+          if (ksteps > 1) pair_flags[(fy * W + fx) >> 1] = 0;
+          continue;
+        }
+        if (a.y_periodic) {                                                               // periodic (:245-247)
+          if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
+          ys = (sr == 0) ? rows_storage - 1 : sr - 1;
+          yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
+        }
       }
       // three 32-bit byte offsets per lane on block-uniform plane bases (scalar base + vector offset
       // addressing: no 64-bit address arithmetic in the vector unit; the x -+ 1 shifts live in the bases)
@@ -213,24 +226,29 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       p[3] = at_byte<f2u>(a.srck[3] + 1, o_here);                                     // :533
       p[6] = at_byte<f2u>(a.srck[6] + 1, o_south);                                    // :536
       p[7] = at_byte<f2u>(a.srck[7] + 1, o_north);                                    // :537
-      if (gx == 0) {                          // x_w wraps to nx-1 (:529)
-        p[1].x = at_byte<float>(a.srck[1] + nx - 1, o_here); p[5].x = at_byte<float>(a.srck[5] + nx - 1, o_south);
-        p[8].x = at_byte<float>(a.srck[8] + nx - 1, o_north);
-      }
-      if (gx == nx - 2) {                     // x_e wraps to 0 (:527-528)
-        p[3].y = at_byte<float>(a.srck[3] + 2 - nx, o_here); p[6].y = at_byte<float>(a.srck[6] + 2 - nx, o_south);
-        p[7].y = at_byte<float>(a.srck[7] + 2 - nx, o_north);
+      if (!inner) {
+        if (gx == 0) {                        // x_w wraps to nx-1 (:529)
+          p[1].x = at_byte<float>(a.srck[1] + nx - 1, o_here); p[5].x = at_byte<float>(a.srck[5] + nx - 1, o_south);
+          p[8].x = at_byte<float>(a.srck[8] + nx - 1, o_north);
+        }
+        if (gx == nx - 2) {                   // x_e wraps to 0 (:527-528)
+          p[3].y = at_byte<float>(a.srck[3] + 2 - nx, o_here); p[6].y = at_byte<float>(a.srck[6] + 2 - nx, o_south);
+          p[7].y = at_byte<float>(a.srck[7] + 2 - nx, o_north);
+        }
       }
       const uint32_t mbits = (at_byte<uint32_t>(a.mask, 4u * (static_cast<uint32_t>(cell) >> 5)) >> (cell & 31)) & 3u;
       f2 out[9];
       // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
       // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
       const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
-                         x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned;
-      acc[0] += finish_pair(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2, owned, out);
+                         (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
+      bool accel_row_here = false;
+      if (tile_accel) accel_row_here = on_accel_row(sr);
+      acc[0] += finish_pair(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned, out);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
+        pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u);
       } else if (owned) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], &at_byte<f2>(a.dstk[k], o_here));
@@ -253,14 +271,19 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
       const int ry = tid / wp, rp = tid - ry * wp;
       const int fx = EX - ex + 2 * rp;
-      int gx = x0 + fx - EX; if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;
 #pragma unroll
       for (int r0 = 0; r0 < rows; r0 += rpp) {
         f2 outs[9];
         int slot = -1;
-        const int fy = EY - ey + r0 + ry;
-        if (ry < rpp && r0 + ry < rows && (a.y_periodic || sy0 + fy - EY < rows_storage)) {   // (same skip as in sub-step 1)
-          const int c = fy * W + fx - rd;
+        const bool in_region = ry < rpp && r0 + ry < rows;
+        // whole waves without work skip the pass; in the others every lane computes (an idle lane on the
+        // region's first row) and only the write is predicated: no per-lane state to merge at the barrier
+        if (__builtin_amdgcn_ballot_w64(in_region) != 0ull) {
+          const int fy = EY - ey + (in_region ? r0 + ry : 0);
+          const int cf = fy * W + fx;                                    // frame position; stored rd (read) / wr (written) lower
+          const uint32_t fl = pair_flags[cf >> 1];
+          const bool lane_on = in_region && (fl & 16u);
+          const int c = cf - rd;
           f2 p[9];
           p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + c);
           p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + c - W);
@@ -271,18 +294,14 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           p[3] = f2{lds[3 * kCells + c + 1], lds[3 * kCells + c + 2]};
           p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
           p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
-          int sr = sy0 + fy - EY;
-          if (a.y_periodic) { if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage; }
-          const int cell = sr * nx + gx;
-          const uint32_t mbits = (at_byte<uint32_t>(a.mask, 4u * (static_cast<uint32_t>(cell) >> 5)) >> (cell & 31)) & 3u;
-          const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
-                             x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned;
-          const double term = finish_pair(p, mbits, a.omega, tile_accel, (!last || a.accel_last) && on_accel_row(sr), a.accel_w1, a.accel_w2,
+          const bool owned = lane_on && (fl & 4u);
+          const double term = finish_pair(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
                                           owned, outs);
 #pragma unroll
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;
-          slot = last ? (owned ? cell : -1) : fy * W + fx - wr;
+          // an owned pair lies inside the grid: its cell index needs no periodic wrap
+          slot = !lane_on ? -1 : last ? (owned ? (sy0 + fy - EY) * nx + x0 + fx - EX : -1) : cf - wr;
         }
         if (!last) {
           __syncthreads();                     // every lane of the pass has read its neighbours

@@ -468,7 +468,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // K steps per pass over HBM (lbm_multi_kernel), measured us/step for K = 2 / 3 / 4 (one-step kernel):
     //   8192x8192 515 / 532 / 556 (853-917)   2048x2048 34.0 / 35.0 / 35.7 (59)
     //   1024x1024 11.4 / 10.0 / 10.2 (13.5)   512x512 3.9 / 3.5 / 3.6 (6.3; lbm_tile_kernel 5.2)
-    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells <= (1u << 21) ? 3 : 2), 0), kMaxMultiSteps);
+    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 3), 0), kMaxMultiSteps);
     c->multi_tiles_x = (p->nx + kMTX - 1) / kMTX;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""A/B of different BUILDS of liblbm_d2q9.so in one process on one GPU (box-to-box spread is ~5 %,
+larger than most kernel changes):
+
+    python scripts/ab_libs.py --grid 8192x8192 --steps 60 --rounds 4 [--env LBM_TUNE_MULTI_K=3] a.so b.so ...
+
+Each library is dlopen'ed privately, gets its own context on the same synthetic deck, and the runs are
+interleaved round-robin; prints device time per step (HIP events inside the library): min / median.
+Keep variant builds under mpilattice-boltzmann_amd/lib/variants/ (git-ignored, travels with gpurun)."""
+import argparse
+import ctypes as C
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import mpilattice_boltzmann_amd as lbm  # noqa: E402  (loads torch's HIP runtime first)
+from mpilattice_boltzmann_amd import _capi  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--grid", default="8192x8192")
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--env", action="append", default=[], help="KEY=VALUE set before every lbm_create")
+ap.add_argument("libs", nargs="+")
+a = ap.parse_args()
+nx, ny = (int(v) for v in a.grid.split("x"))
+for kv in a.env:
+    k, v = kv.split("=")
+    os.environ[k] = v
+p = lbm.Params(nx, ny, a.steps, 10, 0.1, 0.005, 1.85)
+obst = np.ascontiguousarray(lbm.synthetic_obstacles(nx, ny, 0.005, 42, True), dtype=np.int32)
+free_cells = int(obst.size - obst.sum())
+cp = _capi.CParams(p.nx, p.ny, p.max_iters, p.reynolds_dim, p.density, p.accel, p.omega)
+
+ctxs = []
+for path in a.libs:
+    lib = C.CDLL(os.path.abspath(path))
+    for name in ("lbm_create", "lbm_run", "lbm_last_run_kernel_ms", "lbm_destroy", "lbm_last_error"):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _capi._SIGNATURES[name]
+    ctx = C.c_void_p()
+    if lib.lbm_create(C.byref(ctx), C.byref(cp), free_cells, obst.ctypes.data_as(C.POINTER(C.c_int)), 0, ny, 0, a.flags):
+        raise SystemExit(f"{path}: {lib.lbm_last_error().decode()}")
+    ctxs.append((path, lib, ctx))
+
+av = (C.c_float * a.steps)()
+res = {path: [] for path, _, _ in ctxs}
+digest = {}
+for path, lib, ctx in ctxs:
+    lib.lbm_run(ctx, 12, av)
+    digest[path] = bytes(av)[:48]
+for r in range(a.rounds):
+    for path, lib, ctx in ctxs:
+        if lib.lbm_run(ctx, a.steps, av):
+            raise SystemExit(f"{path}: {lib.lbm_last_error().decode()}")
+        ms, n = C.c_double(), C.c_int()
+        lib.lbm_last_run_kernel_ms(ctx, C.byref(ms), C.byref(n))
+        res[path].append(ms.value / a.steps * 1e3)
+ref = digest[ctxs[0][0]]
+for path, lib, ctx in ctxs:
+    v = res[path]
+    same = "av==first" if digest[path] == ref else "av DIFFERS from first"
+    print(f"{os.path.basename(path):40s} min {min(v):8.1f}  med {statistics.median(v):8.1f}  max {max(v):8.1f} us/step   {same}", flush=True)
+    lib.lbm_destroy(ctx)
