@@ -134,8 +134,22 @@ def cpu_baseline(lbm, params, obstacles, target_s: float) -> dict:
     return out
 
 
+# The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version
+# banner at communicator creation on some boxes), so everything else goes to stderr: fd 1 is pointed at
+# fd 2 for the whole run and the line is written to the saved descriptor.
+REAL_STDOUT = 1
+
+
+def quiet_stdout() -> None:
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
 def main() -> None:
     args = parse_args()
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "LBM_FORCE_DEVICE" in os.environ:          # testing aid: several ranks on one device (if the communicator allows it)
@@ -225,7 +239,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lbm, params, obstacles, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -219,8 +219,10 @@ template <int K>
 void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a)
 {
   using G = MultiGeom<K>;
-  if (a.ksteps == K) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
-  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
+  static const size_t pad = static_cast<size_t>(tune_env("LBM_TUNE_MULTI_LDSPAD", 0));   // experiment: fewer blocks per CU
+  const size_t lds = std::min<size_t>(G::lds_bytes + pad, 65536);
+  if (a.ksteps == K) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), lds, s>>>(a);
+  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), lds, s>>>(a);
 }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
@@ -363,9 +365,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && ny_local >= 2 * kMTY && fits_u32 &&
       (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX))) {
     // measured on a 1-rank ring with the packed exchange, us/step for K = 2 / 3 / 4 (one-step loop):
-    //   8192x4096 rows 247 / 255 / 268   8192x1024 rows 72.5 / 70.1 / 72.3 (116)   1024x512 rows 25.7 / 17.6 / 15.0
-    //   1024x128 rows 25.0 / 18.4 / 14.4 (37)
-    const int by_size = c->ncells < (1u << 21) ? 4 : (c->ncells < (1u << 24) ? 3 : 2);
+    //   8192x4096 rows 243 / 182 / 199   8192x2048 rows 122 / 92.6 / 103   8192x1024 rows 66.2 / 52.5 / 55.9 (116)
+    //   1024x128 rows 26.1 / 18.8 / 14.7 (37)
+    const int by_size = c->ncells < (1u << 21) ? 4 : 3;
     const int k = tune_env("LBM_TUNE_MACRO_K", by_size);
     if (k > 0) { c->multi_K = std::min(k, kMaxMultiSteps); c->ghost = c->multi_K; }
   }
@@ -466,8 +468,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
     // sticks out of the grid (periodic images: computed, not kept)
     // K steps per pass over HBM (lbm_multi_kernel), measured us/step for K = 2 / 3 / 4 (one-step kernel):
-    //   8192x8192 515 / 532 / 556 (853-917)   2048x2048 34.0 / 35.0 / 35.7 (59)
-    //   1024x1024 11.4 / 10.0 / 10.2 (13.5)   512x512 3.9 / 3.5 / 3.6 (6.3; lbm_tile_kernel 5.2)
+    //   8192x8192 500 / 360 / 405 (853-917)   2048x2048 33.5 / 25.5 / 27.4 (59)
+    //   1024x1024 11.2 / 8.3 / 8.5 (13.5)   512x512 3.7 / 3.4 / 3.3 (6.3; lbm_tile_kernel 5.2)
+    // K = 2 is HBM-bound, K = 4 instruction-bound at 2 blocks per CU (60 KB frames); K = 3 sits at both limits
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 3), 0), kMaxMultiSteps);
     c->multi_tiles_x = (p->nx + kMTX - 1) / kMTX;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
