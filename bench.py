@@ -198,6 +198,7 @@ def main() -> None:
 
     kernel_ms, launches = sim.partition.last_run_kernel_ms()
     desc = sim.partition.describe()
+    macro_k = sim.partition.macro_steps
     sim.close()
 
     if rank == 0:
@@ -228,10 +229,13 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny,
-                       "partitioning": ("single GPU" if not args.ring else "1-rank ring (self exchange over RCCL)") if world == 1 else f"{world} row blocks, 1-row halo exchange (RCCL send/recv, {args.exchange} loop), one all-reduce after the loop"},
+                       "partitioning": ("single GPU" if not args.ring else "1-rank ring (self exchange over RCCL)") if world == 1 else f"{world} row blocks, one {max(macro_k, 1)}-row halo exchange per {max(macro_k, 1)} steps (RCCL send/recv, {args.exchange} loop), one all-reduce after the loop"},
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": desc["kernel"],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_GBps": None if traffic is None else traffic / avg_launch_s / 1e9,      # physical HBM rate
+                         "traffic_frac": None if traffic is None else traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                         "kernel": desc["kernel"],
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_cell_step": ALGO_BYTES_PER_CELL,
                          "note": "frac > 1 is possible: the 108 B/cell-step convention assumes one pass over HBM per step; "
