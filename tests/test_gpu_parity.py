@@ -501,6 +501,102 @@ def test_k_steps_per_pass_kernel(lbm, oracle, digests, monkeypatch, name, steps,
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
+def _k_step_partitions_in_process(lbm, parts, steps, K):
+    """Several K-step partitions of one grid on one GPU, ghost rows exchanged by device copies
+    (lbm_macro_exchange_local) in the order of the native loop; returns the summed per-step tot_u."""
+    import torch
+    size = len(parts)
+    tstream = torch.cuda.Stream(torch.device("cuda", 0))
+    st = tstream.cuda_stream
+    with torch.cuda.stream(tstream):
+        for part in parts:
+            part.macro_prepare(steps, st)
+        done = 0
+        while done < steps:
+            for r, part in enumerate(parts):
+                part.macro_receive_from(parts[(r - 1) % size], lbm.NORTH, st)    # southern neighbour's top rows
+                part.macro_receive_from(parts[(r + 1) % size], lbm.SOUTH, st)    # northern neighbour's bottom rows
+            for part in parts:
+                part.macro_interior(st)
+                part.macro_edge(st)
+            for part in parts:
+                part.macro_finish(st)
+            done += K
+        sums = sum(part.step_collect(steps, st) for part in parts)
+    tstream.synchronize()
+    return sums
+
+
+def _stress_deck(lbm, kind, nx, ny):
+    """Decks that take the rare paths of lbm_multi_kernel: no obstacle anywhere (the bounce-back branch
+    is never entered), every second cell blocked (always entered, also on the accelerate row), row
+    ny-2 walled off (accelerate_flow finds no free cell), an acceleration so strong that the
+    positivity test of d2q9-bgk.c:461-463 fails for most cells, relaxation at both ends of the range."""
+    omega, accel, density = 1.85, 0.005, 0.1
+    obst = np.zeros((ny, nx), np.int32)
+    if kind == "open":
+        pass
+    elif kind == "dense":
+        obst = lbm.synthetic_obstacles(nx, ny, 0.5, 3, False)
+    elif kind == "accel_row_blocked":
+        obst = lbm.synthetic_obstacles(nx, ny, 0.01, 5, True)
+        obst[ny - 2, :] = 1
+    elif kind == "strong_accel":
+        obst = lbm.synthetic_obstacles(nx, ny, 0.02, 9, False)
+        accel = 0.9
+    elif kind == "omega_low":
+        obst = lbm.synthetic_obstacles(nx, ny, 0.02, 11, True)
+        omega, density = 0.6, 1.0
+    elif kind == "omega_high":
+        obst = lbm.synthetic_obstacles(nx, ny, 0.02, 13, True)
+        omega, accel = 1.99, 0.01
+    if obst.all():
+        obst[1, 1] = 0
+    return lbm.Params(nx, ny, 40, 8, density, accel, omega), obst
+
+
+STRESS = ["open", "dense", "accel_row_blocked", "strong_accel", "omega_low", "omega_high"]
+
+
+@pytest.mark.parametrize("K", [2, 3, 4])
+@pytest.mark.parametrize("kind", STRESS)
+def test_multi_kernel_rare_paths(lbm, oracle, monkeypatch, kind, K):
+    """Whole periodic grid (edge tiles only at 256x64, inner tiles too at 448x112) through
+    lbm_multi_kernel<K>: uniform branches for accelerate_flow / bounce-back / inner tiles, pair flags."""
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", str(K))
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    for nx, ny in ((256, 64), (448, 112)):
+        p, obst = _stress_deck(lbm, kind, nx, ny)
+        s = lbm.Simulation(p, obst)
+        assert s.partition.describe()["kernel"] == f"lbm_multi_kernel<{K}>"
+        av = np.concatenate([s.run(29), s.run(11)])
+        cells = s.local_cells()
+        s.close()
+        ref_cells, _, ref_exact = oracle.run(p, obst, 40, nthreads=4)
+        assert np.array_equal(bits(cells), bits(ref_cells)), (kind, nx, ny)
+        assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("kind", STRESS)
+def test_k_step_partitions_rare_paths(lbm, oracle, monkeypatch, kind):
+    """The same decks as K-step row partitions exchanged in-process (3 partitions of 448x112: the
+    accelerate row lies in one partition's owned rows and in its neighbour's ghost rows)."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "3")
+    p, obst = _stress_deck(lbm, kind, 448, 112)
+    ny_local, displs = lbm.decompose(p.ny, 3)
+    free = int(obst.size - obst.sum())
+    parts = [lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r], obstacles_global=obst) for r in range(3)]
+    assert all(q.macro_steps == 3 for q in parts)
+    sums = _k_step_partitions_in_process(lbm, parts, 40, 3)
+    cells = np.concatenate([q.get_cells() for q in parts], axis=0)
+    for q in parts:
+        q.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 40, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells)), kind
+    av = sums * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < 1e-12
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 61), ("128x128", 50), ("1024x1024_t200", 30)])
 def test_k_step_mode_on_a_ring_of_one(lbm, oracle, digests, monkeypatch, name, steps, K):
@@ -523,31 +619,13 @@ def test_k_step_mode_on_a_ring_of_one(lbm, oracle, digests, monkeypatch, name, s
 def test_k_step_mode_with_several_partitions(lbm, oracle, digests, monkeypatch, name, size, K):
     """Several K-step partitions of one grid on one GPU, ghost rows exchanged by device copies
     (lbm_macro_exchange_local) in the order of the native loop: must equal the single-partition run."""
-    import torch
     monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
     p, obst, free = load_case(lbm, digests, name)
     steps = min(p.max_iters, 45)
     ny_local, displs = lbm.decompose(p.ny, size)
     parts = [lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r], obstacles_global=obst) for r in range(size)]
     assert all(part.macro_steps == K for part in parts)
-    tstream = torch.cuda.Stream(torch.device("cuda", 0))
-    st = tstream.cuda_stream
-    with torch.cuda.stream(tstream):
-        for part in parts:
-            part.macro_prepare(steps, st)
-        done = 0
-        while done < steps:
-            for r, part in enumerate(parts):
-                part.macro_receive_from(parts[(r - 1) % size], lbm.NORTH, st)    # southern neighbour's top rows
-                part.macro_receive_from(parts[(r + 1) % size], lbm.SOUTH, st)    # northern neighbour's bottom rows
-            for part in parts:
-                part.macro_interior(st)
-                part.macro_edge(st)
-            for part in parts:
-                part.macro_finish(st)
-            done += K
-        sums = sum(part.step_collect(steps, st) for part in parts)
-    tstream.synchronize()
+    sums = _k_step_partitions_in_process(lbm, parts, steps, K)
     cells = np.concatenate([part.get_cells() for part in parts], axis=0)
     ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
     assert np.array_equal(bits(cells), bits(ref_cells))
