@@ -223,4 +223,57 @@ __device__ __forceinline__ void accelerate_cell(float (&out)[9], float w1, float
   }
 }
 
+// base + 32-bit byte offset: the form hipcc turns into "global_load/store v_off, s[base]" (needs < 4 GiB per grid)
+template <typename V, typename B>
+__device__ __forceinline__ auto& at_byte(B* base, uint32_t byte_off)
+{
+  using P = std::conditional_t<std::is_const_v<B>, const V, V>;
+  using C = std::conditional_t<std::is_const_v<B>, const char, char>;
+  return *reinterpret_cast<P*>(reinterpret_cast<C*>(base) + byte_off);
+}
+
+// Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
+// p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
+// Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
+// double-precision sqrt is a tenth of the cell's instructions).
+// tile_accel is block-uniform: false for the tiles whose frame does not meet row ny-2, which then skip
+// the accelerate_flow code instead of predicating it away in every pair.
+__device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
+                                              bool want_term, f2 (&out)[9])
+{
+  f2 o[9], msq, rinv;
+  relax_core<f2>(t, omega, o, msq, rinv);                               // :546-666 on both cells at once (v_pk_*_f32)
+  // bounce-back select (d2q9-bgk.c:687-695) and the next step's accelerate_flow (:457-469), per cell
+  static constexpr int opp[9] = {0, 3, 4, 1, 2, 7, 8, 5, 6};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out[k] = o[k];
+  if (__builtin_amdgcn_ballot_w64(mbits != 0u) != 0ull) {          // wave-uniform: most waves hold no obstacle
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool blocked = (mbits >> j) & 1u;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) out[k][j] = blocked ? t[opp[k]][j] : o[k][j];
+    }
+  }
+  if (tile_accel) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float r[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) r[k] = out[k][j];
+      if (accel && !((mbits >> j) & 1u)) accelerate_cell(r, w1, w2);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) out[k][j] = r[k];
+    }
+  }
+  double term = 0.0;
+  if (want_term) {
+    const double t0 = sqrt_of_float(msq.x) * static_cast<double>(rinv.x);   // :667
+    const double t1 = sqrt_of_float(msq.y) * static_cast<double>(rinv.y);
+    term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
+  }
+  return term;
+}
+
+
 }  // namespace

@@ -445,10 +445,10 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   // temporally blocked form: whole periodic grids whose edges are multiples of the tile edge and
   // that are small enough to be launch-latency-bound (measured cross-over)
   {
-    // geometry by size, measured on MI355X (us/step; one-step kernels 3.4 / 3.5 / 4.0 / 6.3):
-    //   128x128: <8,4> 1.6, <16,8> 1.9 | 128x256: <16,8> 2.0, <8,4> 2.1 | 256x256: <16,4> 2.5, <8,4> 2.9
-    //   512x512: <16,4> 5.2 | 1024x1024: slower than the one-step kernel (13.6)
-    const int by_size = c->ncells <= 16384 ? 84 : (c->ncells <= 32768 ? 168 : 164);
+    // geometry by size, measured on MI355X with x-pair lanes (us/step for <8,4> / <8,8> / <16,4> / <16,8>;
+    // one-step kernels 3.4 / 3.5 / 4.0):  128x128 1.8 / 1.5 / 2.0 / 1.7 | 128x256 2.4 / 2.1 / 2.1 / 1.8 |
+    // 256x256 3.4 / 3.4 / 2.4 / 2.0   (one cell per lane: 1.6 / 1.5 / 1.8 / 1.8 | 2.0 / 2.1 / 2.0 / 1.9 | 2.8 / 3.7 / 2.3 / 2.1)
+    const int by_size = c->ncells <= 16384 ? 88 : 168;
     const int geom = tune_env("LBM_TUNE_TILE_GEOM", by_size);   // T*10 + H
     c->tile_T = geom / 10; c->tile_H = geom % 10;
     if (!((c->tile_T == 16 || c->tile_T == 8) && (c->tile_H == 8 || c->tile_H == 4))) { c->tile_T = 16; c->tile_H = 4; }
