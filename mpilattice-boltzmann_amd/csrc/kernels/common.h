@@ -223,6 +223,12 @@ __device__ __forceinline__ void accelerate_cell(float (&out)[9], float w1, float
   }
 }
 
+// i / d for 0 <= i < 1024, 4 <= d <= 44: one full-rate 24-bit multiply instead of an integer division
+__device__ __forceinline__ int small_div(int i, int d)
+{
+  return static_cast<int>(__umul24(static_cast<unsigned>(i), static_cast<unsigned>((65536 + d - 1) / d)) >> 16);
+}
+
 // base + 32-bit byte offset: the form hipcc turns into "global_load/store v_off, s[base]" (needs < 4 GiB per grid)
 template <typename V, typename B>
 __device__ __forceinline__ auto& at_byte(B* base, uint32_t byte_off)
@@ -234,12 +240,12 @@ __device__ __forceinline__ auto& at_byte(B* base, uint32_t byte_off)
 
 // Two x-adjacent cells: relaxation / bounce-back select, next step's accelerate_flow, sum|u| terms.
 // p[k] = streamed-in population k of the pair; mbits = their two obstacle bits.
-// Returns the pair's sum|u| contribution (0 unless want_term: ghost-ring cells do not count, and the
-// double-precision sqrt is a tenth of the cell's instructions).
+// Returns the pair's sum|u| contribution; bit j of `skip` drops cell j from it (obstacles, cells of the
+// ghost ring: they do not count, and the double-precision sqrt is a tenth of the cell's instructions).
 // tile_accel is block-uniform: false for the tiles whose frame does not meet row ny-2, which then skip
 // the accelerate_flow code instead of predicating it away in every pair.
 __device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
-                                              bool want_term, f2 (&out)[9])
+                                              uint32_t skip, f2 (&out)[9])
 {
   f2 o[9], msq, rinv;
   relax_core<f2>(t, omega, o, msq, rinv);                               // :546-666 on both cells at once (v_pk_*_f32)
@@ -267,10 +273,10 @@ __device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, 
     }
   }
   double term = 0.0;
-  if (want_term) {
+  if (skip != 3u) {
     const double t0 = sqrt_of_float(msq.x) * static_cast<double>(rinv.x);   // :667
     const double t1 = sqrt_of_float(msq.y) * static_cast<double>(rinv.y);
-    term = ((mbits & 1u) ? 0.0 : t0) + ((mbits & 2u) ? 0.0 : t1);
+    term = ((skip & 1u) ? 0.0 : t0) + ((skip & 2u) ? 0.0 : t1);
   }
   return term;
 }

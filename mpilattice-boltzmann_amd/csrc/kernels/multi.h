@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
                          (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
-      acc[0] += finish_pair(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned, out);
+      acc[0] += finish_pair(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
           const bool owned = lane_on && (fl & 4u);
           const double term = finish_pair(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
-                                          owned, outs);
+                                          owned ? (fl & 3u) : 3u, outs);
 #pragma unroll
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;

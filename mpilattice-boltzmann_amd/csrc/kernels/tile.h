@@ -9,33 +9,34 @@ namespace {
 // Temporally blocked form for launch-latency-bound grids (the three small shipped decks).
 //
 // A step of a <= 64 K-cell grid takes less time to compute than a kernel boundary costs, so one
-// launch here advances the lattice by up to H steps (e.g. T = 16, H = 8: a 512-lane block loads a 32x32
-// region (a 16x16 owned tile + an 8-cell ghost ring, periodic in x and y) into LDS, every lane keeps
-// ONE x-PAIR of region cells for the whole launch, and sub-step s recomputes the region shrunk by s
-// cells from the LDS copy of sub-step s-1 (double-buffered, one barrier per sub-step).  Ghost cells are
-// computed redundantly by neighbouring blocks with the same arithmetic, so no block ever waits for
-// another.  Per-step sum|u| is taken over owned cells only; accelerate_flow is applied to row ny-2
-// (ghost copies too) between sub-steps exactly as between launches of the one-step kernels.  Results
-// are bit-identical to the one-step kernels (same relax_core, same order of steps).
+// launch here advances the lattice by up to H steps: a block loads an R x R region (R = T + 2H: a T x T
+// owned tile + an H-cell ghost ring, periodic in x and y) into LDS, and sub-step s recomputes the
+// region shrunk by s cells from the LDS copy of sub-step s-1 (two buffers, one barrier per sub-step).
+// Ghost cells are computed redundantly by neighbouring blocks with the same arithmetic, so no block
+// ever waits for another.  Per-step sum|u| is taken over owned cells only; accelerate_flow is applied
+// to row ny-2 (ghost copies too) between sub-steps exactly as between launches of the one-step
+// kernels.  Results are bit-identical to the one-step kernels (same relax_core, same order of steps).
 //
-// Pairs: with one cell per lane a <16,8> block was 16 waves on the 4 SIMDs of its CU and a sub-step
-// cost four waves' worth of instructions per SIMD; a lane that owns two x-adjacent cells runs the
-// packed arithmetic of lbm_multi_kernel (finish_pair), so the same block is 8 waves.  A pair that
-// straddles the edge of the shrinking region is computed whole; its outer cell is never read by a
-// cell that is still needed.
+// Work per sub-step is what bounds this kernel (one block = one CU: its 4 SIMDs issue every wave
+// that holds a live lane), so the lanes are dealt anew in every sub-step: lane i takes the i-th
+// x-pair of the CURRENT region (packed arithmetic: finish_pair), live lanes fill whole waves from
+// wave 0 up, and the rest of the block skips the sub-step.  <16,8>: 39 wave-passes per 8 steps instead
+// of 52 with a fixed lane -> cell assignment (and 104 with one cell per lane).  The region's left edge
+// alternates between even and odd x, so LDS accesses are pairs of dwords rather than 8-byte words.
+// What a lane needs to know about its cells it reads from a flag byte per region cell.
 // ------------------------------------------------------------------------------------------------
 // Geometry is a template parameter pair: T = owned tile edge, H = ghost ring = max steps per launch
-// (both even); the region edge is R = T + 2H and the block has R*R/2 lanes.
+// (both even); the block has R*R/2 lanes (the load phase: one aligned x-pair per lane).
 constexpr int kMaxTileSteps = 8;
 
 template <int T, int H>
 struct TileGeom {
   static constexpr int R = T + 2 * H;
-  static constexpr int RP = R / 2;                  // pairs per region row
+  static constexpr int RP = R / 2;                  // aligned pairs per region row
   static constexpr int cells = R * R;
   static constexpr int lanes = RP * R;
   static constexpr int waves = (lanes + 63) / 64;
-  static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * cells + sizeof(double) * H * waves;
+  static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * cells + sizeof(double) * H * waves + cells;   // + flag bytes
   static_assert(lanes <= 1024 && H <= kMaxTileSteps && T % 2 == 0 && H % 2 == 0, "unsupported tile geometry");
 };
 
@@ -57,13 +58,14 @@ struct TileArgs {
   int* counter;
 };
 
-template <int T, int H>
+template <int T, int H, bool FULL>   // FULL: this launch does exactly H steps (region sizes are compile-time constants)
 __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel(const TileArgs a)
 {
   using G = TileGeom<T, H>;
   constexpr int R = G::R, RP = G::RP, kCells = G::cells, kLanes = G::lanes, kWaves = G::waves;
-  extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][9][R*R] floats, then reduction scratch
+  extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][9][R*R] floats, reduction scratch, flag bytes
   double* red = reinterpret_cast<double*>(lds + 2 * 9 * kCells);    // [H][kWaves]
+  uint8_t* cell_flags = reinterpret_cast<uint8_t*>(red + H * kWaves);   // per region cell: bit 0 obstacle, 1 owned, 2 on row ny-2
   const int tid = threadIdx.x;
 
   if (blockIdx.x == 0) {
@@ -88,15 +90,6 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
 
   const int tile = blockIdx.x - 1;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int ry = tid / RP, rx = 2 * (tid - ry * RP);                  // this lane's pair: region cells (rx, ry), (rx+1, ry)
-  // global cells of this lane, periodic (d2q9-bgk.c:527-529 in x; :245-247 one-rank ring in y); nx, T and H
-  // are even, so a pair never straddles the wrap and its first cell has an even index
-  int gx = (tx * T - H + rx) % a.nx; if (gx < 0) gx += a.nx;
-  int gy = (ty * T - H + ry) % a.ny; if (gy < 0) gy += a.ny;
-  const int cell = gy * a.nx + gx;
-  const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
-  const bool owned = rx >= H && rx < H + T && ry >= H && ry < H + T;
-  const bool on_accel_row = gy == a.accel_row;
   // does the region of this tile meet row ny-2 at all ?  (block-uniform; the others skip accelerate_flow)
   bool tile_accel;
   {
@@ -105,32 +98,47 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
     tile_accel = d < R || a.ny < R;
   }
 
-  float* bufA = lds;
-  float* bufB = lds + 9 * kCells;
-  const int c = ry * R + rx;
+  // ---- load: lane = one aligned x-pair of the region, periodic (d2q9-bgk.c:527-529 in x; :245-247 one-rank ring
+  // in y); nx, T and H are even, so a pair never straddles the wrap and its first cell has an even index
+  {
+    const int ry = tid / RP, rx = 2 * (tid - ry * RP);
+    int gx = (tx * T - H + rx) % a.nx; if (gx < 0) gx += a.nx;
+    int gy = (ty * T - H + ry) % a.ny; if (gy < 0) gy += a.ny;
+    const int cell = gy * a.nx + gx;
+    const uint32_t mbits = (a.mask[cell >> 5] >> (cell & 31)) & 3u;
+    const uint32_t common = ((rx >= H && rx < H + T && ry >= H && ry < H + T) ? 2u : 0u) | (gy == a.accel_row ? 4u : 0u);
+    const int c = ry * R + rx;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(bufA + k * kCells + c) = *reinterpret_cast<const f2*>(a.src + k * a.ps + cell);
+    for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + c) = *reinterpret_cast<const f2*>(a.src + k * a.ps + cell);
+    *reinterpret_cast<uint16_t*>(cell_flags + c) = static_cast<uint16_t>(((mbits & 1u) | common) | ((((mbits >> 1) & 1u) | common) << 8));
+  }
   __syncthreads();
 
   double acc[H];
 #pragma unroll
   for (int i = 0; i < H; ++i) acc[i] = 0.0;
-  f2 out[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) out[k] = f2{0.0f, 0.0f};
 
-  const int k_total = a.ksteps;
-#pragma unroll 1
-  for (int s = 1; s <= k_total; ++s) {
-    // cells still needed after this sub-step: the owned tile expanded by (k_total - s); a pair with one
-    // such cell is computed whole
-    const int e = k_total - s;
-    const bool active = rx + 1 >= H - e && rx < H + T + e && ry >= H - e && ry < H + T + e;
-    if (active) {
-      f2 p[9];                                                                   // d2q9-bgk.c:530-538
-      p[0] = *reinterpret_cast<const f2*>(bufA + 0 * kCells + c);
-      p[2] = *reinterpret_cast<const f2*>(bufA + 2 * kCells + c - R);
-      p[4] = *reinterpret_cast<const f2*>(bufA + 4 * kCells + c + R);
+  const int k_total = FULL ? H : a.ksteps;
+  // One sub-step; S is a compile-time constant (the sub-steps are unrolled: buffer roles and the accumulator slot fold).
+  auto substep = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value;
+    const float* bufA = lds + ((S & 1) ? 0 : 9 * kCells);
+    float* bufB = lds + ((S & 1) ? 9 * kCells : 0);
+    // cells still needed after this sub-step: the owned tile expanded by e = k_total - S
+    const int e = k_total - S;
+    const int w = T / 2 + e;                          // pairs per row of that region
+    if (tid < w * (T + 2 * e)) {
+      const int ry = small_div(tid, w), rp = tid - ry * w;
+      const int x = H - e + 2 * rp, y = H - e + ry;   // region cells (x, y), (x+1, y)
+      const int c = y * R + x;
+      const uint32_t fl0 = cell_flags[c], fl1 = cell_flags[c + 1];
+      const uint32_t mbits = (fl0 & 1u) | ((fl1 & 1u) << 1);
+      // a pair that starts on an odd x may straddle the edge of the owned tile: per-cell skip bits
+      const uint32_t skip = (((fl0 & 1u) | ((fl0 & 2u) ? 0u : 1u))) | (((fl1 & 1u) | ((fl1 & 2u) ? 0u : 1u)) << 1);
+      f2 p[9], out[9];                                                           // d2q9-bgk.c:530-538
+      p[0] = f2{bufA[0 * kCells + c], bufA[0 * kCells + c + 1]};
+      p[2] = f2{bufA[2 * kCells + c - R], bufA[2 * kCells + c - R + 1]};
+      p[4] = f2{bufA[4 * kCells + c + R], bufA[4 * kCells + c + R + 1]};
       p[1] = f2{bufA[1 * kCells + c - 1], bufA[1 * kCells + c]};
       p[5] = f2{bufA[5 * kCells + c - R - 1], bufA[5 * kCells + c - R]};
       p[8] = f2{bufA[8 * kCells + c + R - 1], bufA[8 * kCells + c + R]};
@@ -138,26 +146,31 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
       p[6] = f2{bufA[6 * kCells + c - R + 1], bufA[6 * kCells + c - R + 2]};
       p[7] = f2{bufA[7 * kCells + c + R + 1], bufA[7 * kCells + c + R + 2]};
       // relaxation, bounce-back (:687-695), accelerate_flow of the following step (:457-469), sum|u| terms
-      const double term = finish_pair(p, mbits, a.omega, tile_accel, on_accel_row && (s < k_total || a.accel_last),
-                                      a.accel_w1, a.accel_w2, owned, out);
-      if (owned) {
+      acc[S - 1] = finish_pair(p, mbits, a.omega, tile_accel, (fl0 & 4u) && (S < k_total || a.accel_last), a.accel_w1, a.accel_w2,
+                               skip, out);
+      if (S < k_total) {
 #pragma unroll
-        for (int i = 0; i < H; ++i)
-          if (i == s - 1) acc[i] = term;
-      }
-      if (s < k_total) {
+        for (int k = 0; k < 9; ++k) { bufB[k * kCells + c] = out[k].x; bufB[k * kCells + c + 1] = out[k].y; }
+      } else {
+        // last sub-step: the region is the owned tile (x = H + 2 rp, y = H + ry), inside the grid
+        const int cell = (ty * T + ry) * a.nx + tx * T + 2 * rp;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(bufB + k * kCells + c) = out[k];
+        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(a.dst + k * a.ps + cell) = out[k];
       }
     }
-    __syncthreads();
-    float* sw = bufA; bufA = bufB; bufB = sw;
+    if (S < k_total) __syncthreads();
+  };
+  if (1 <= k_total) substep(std::integral_constant<int, 1>{});
+  if (2 <= k_total) substep(std::integral_constant<int, 2>{});
+  if (3 <= k_total) substep(std::integral_constant<int, 3>{});
+  if (4 <= k_total) substep(std::integral_constant<int, 4>{});
+  if constexpr (H >= 8) {
+    if (5 <= k_total) substep(std::integral_constant<int, 5>{});
+    if (6 <= k_total) substep(std::integral_constant<int, 6>{});
+    if (7 <= k_total) substep(std::integral_constant<int, 7>{});
+    if (8 <= k_total) substep(std::integral_constant<int, 8>{});
   }
-
-  if (owned) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(a.dst + k * a.ps + cell) = out[k];
-  }
+  static_assert(H == 4 || H == 8, "sub-steps are unrolled for H = 4 and 8");
 
   // per-step sums over the owned cells of this tile: wave trees, then one lane per step over the waves
   const int ntiles = gridDim.x - 1;

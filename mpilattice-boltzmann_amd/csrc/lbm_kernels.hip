@@ -259,7 +259,8 @@ template <int T, int H>
 void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a)
 {
   using G = TileGeom<T, H>;
-  lbm_tile_kernel<T, H><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+  if (a.ksteps == H) lbm_tile_kernel<T, H, true><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+  else lbm_tile_kernel<T, H, false><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
 }
 
 int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
@@ -445,9 +446,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   // temporally blocked form: whole periodic grids whose edges are multiples of the tile edge and
   // that are small enough to be launch-latency-bound (measured cross-over)
   {
-    // geometry by size, measured on MI355X with x-pair lanes (us/step for <8,4> / <8,8> / <16,4> / <16,8>;
-    // one-step kernels 3.4 / 3.5 / 4.0):  128x128 1.8 / 1.5 / 2.0 / 1.7 | 128x256 2.4 / 2.1 / 2.1 / 1.8 |
-    // 256x256 3.4 / 3.4 / 2.4 / 2.0   (one cell per lane: 1.6 / 1.5 / 1.8 / 1.8 | 2.0 / 2.1 / 2.0 / 1.9 | 2.8 / 3.7 / 2.3 / 2.1)
+    // geometry by size, measured on MI355X (us/step for <8,4> / <8,8> / <16,4> / <16,8>; one-step kernels
+    // 3.4 / 3.5 / 4.0):  128x128 1.7 / 1.4 / 1.8 / 1.6 | 128x256 2.2 / 1.8 / 1.9 / 1.7 | 256x256 3.4 / 3.0 / 2.2 / 1.9
     const int by_size = c->ncells <= 16384 ? 88 : 168;
     const int geom = tune_env("LBM_TUNE_TILE_GEOM", by_size);   // T*10 + H
     c->tile_T = geom / 10; c->tile_H = geom % 10;
@@ -480,8 +480,11 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // up to 74 KB of dynamic LDS per block (two 9 x R x R float buffers): above the 64 KB default limit
     {
       using G168 = TileGeom<16, 8>;
-      auto* k168 = &lbm_tile_kernel<16, 8>;
+      auto* k168 = &lbm_tile_kernel<16, 8, true>;
+      auto* k168t = &lbm_tile_kernel<16, 8, false>;
       HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k168), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(G168::lds_bytes)));
+      HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k168t), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(G168::lds_bytes)));
     }
   }
