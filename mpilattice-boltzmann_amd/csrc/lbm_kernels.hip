@@ -219,10 +219,8 @@ template <int K>
 void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a)
 {
   using G = MultiGeom<K>;
-  static const size_t pad = static_cast<size_t>(tune_env("LBM_TUNE_MULTI_LDSPAD", 0));   // experiment: fewer blocks per CU
-  const size_t lds = std::min<size_t>(G::lds_bytes + pad, 65536);
-  if (a.ksteps == K) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), lds, s>>>(a);
-  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), lds, s>>>(a);
+  if (a.ksteps == K) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
+  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
 }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.

@@ -21,7 +21,7 @@ a = ap.parse_args()
 nx, ny = (int(v) for v in a.grid.split("x"))
 p = lbm.Params(nx, ny, a.steps, 10, 0.1, 0.005, 1.85)
 obst = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
-KNOBS = ["LBM_TUNE_MULTI_LDSPAD", "LBM_TUNE_MAXBLOCKS", "LBM_TUNE_SKEW", "LBM_TUNE_VARIANT", "LBM_TUNE_BLOCK", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MULTI_K", "LBM_TUNE_MULTI_REMAP", "LBM_TUNE_MULTI_QUAD", "LBM_TUNE_MACRO_K"]
+KNOBS = ["LBM_TUNE_MAXBLOCKS", "LBM_TUNE_SKEW", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MULTI_K", "LBM_TUNE_MULTI_REMAP", "LBM_TUNE_MACRO_K"]
 res = {c: [] for c in a.configs}
 for r in range(a.rounds):
     for cfg in a.configs:
