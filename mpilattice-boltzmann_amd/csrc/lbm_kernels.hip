@@ -453,7 +453,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   }
   c->n_tiles = (p->nx % c->tile_T == 0 && ny_local % c->tile_T == 0) ? (p->nx / c->tile_T) * (ny_local / c->tile_T) : 0;
   c->tile_kernel = self_periodic && c->n_tiles > 0 &&
-                   c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 65536));   // 512x512: lbm_multi_kernel<3> 3.5 us/step vs 5.2 here
+                   c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 131072));  // us/step here vs lbm_multi_kernel<3>: 256x256 1.9 / 3.1, 512x256 2.8 / 3.2, 384x384 3.6 / 3.2, 512x512 4.5 / 3.3
   if (c->ghost > 0) {
     const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
