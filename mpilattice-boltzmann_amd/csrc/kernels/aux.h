@@ -83,13 +83,15 @@ __global__ void lbm_pack_halo_kernel(const float* grid, size_t ps, int nx, int n
 // buf layout: [dir][plane][K*nx].  rows_a / rows_b = storage row where direction 0 / 1's K rows start.
 __global__ void lbm_macro_pack_kernel(const float* grid, float* buf, size_t ps, int nfloats /* K*nx */, size_t row_a, size_t row_b, int nx, int unpack)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // float4 index within one plane's K rows
+  // float2 granularity: nx is even in K-step mode, so K*nx and every row offset are multiples of 2 floats
+  // (float4 dropped / overran the last two floats of a message when K*nx % 4 == 2, e.g. K = 3, nx = 206)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // float2 index within one plane's K rows
   const int plane = blockIdx.y, dir = blockIdx.z;
-  if (i * 4 >= nfloats) return;
-  const size_t goff = plane * ps + (dir == 0 ? row_a : row_b) * nx + static_cast<size_t>(i) * 4;
-  const size_t boff = (static_cast<size_t>(dir) * 9 + plane) * nfloats + static_cast<size_t>(i) * 4;
-  if (unpack) *reinterpret_cast<f4*>(const_cast<float*>(grid) + goff) = *reinterpret_cast<const f4*>(buf + boff);
-  else *reinterpret_cast<f4*>(buf + boff) = *reinterpret_cast<const f4*>(grid + goff);
+  if (i * 2 >= nfloats) return;
+  const size_t goff = plane * ps + (dir == 0 ? row_a : row_b) * nx + static_cast<size_t>(i) * 2;
+  const size_t boff = (static_cast<size_t>(dir) * 9 + plane) * nfloats + static_cast<size_t>(i) * 2;
+  if (unpack) *reinterpret_cast<f2*>(const_cast<float*>(grid) + goff) = *reinterpret_cast<const f2*>(buf + boff);
+  else *reinterpret_cast<f2*>(buf + boff) = *reinterpret_cast<const f2*>(grid + goff);
 }
 
 // av_velocity (d2q9-bgk.c:716-751): per-cell float arithmetic as the reference, double accumulation.

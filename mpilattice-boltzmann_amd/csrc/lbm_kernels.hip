@@ -804,7 +804,7 @@ void* lbm_macro_pack_ptr(lbm_ctx* c, int dir, int incoming)
 static int macro_pack_launch(lbm_ctx* c, bool unpack, hipStream_t s)
 {
   const int nfloats = c->ghost * c->p.nx;
-  const dim3 grid((nfloats / 4 + 255) / 256, 9, 2);
+  const dim3 grid((nfloats / 2 + 255) / 256, 9, 2);
   // outgoing: first K owned rows (dir 0, south) and last K owned rows (dir 1, north);
   // incoming: ghost rows below (from the south, dir 0) and above (from the north, dir 1)
   const size_t row_a = unpack ? 0 : static_cast<size_t>(c->ghost);
