@@ -21,9 +21,66 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K"]
+
+
+def run_partitions(p, obst, size, steps, kstep):
+    """`size` row partitions of one grid on one GPU, exchanged by device copies in the order of the step loops."""
+    import torch
+    free = int(obst.size - obst.sum())
+    ny_local, displs = lbm.decompose(p.ny, size)
+    dev = torch.device("cuda", 0)
+    if kstep:
+        parts = [lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r], obstacles_global=obst) for r in range(size)]
+        K = parts[0].macro_steps
+        if K == 0 or any(q.macro_steps != K for q in parts):
+            for q in parts:
+                q.close()
+            return None, None
+    else:
+        parts = [lbm.Partition(p, free, obst[displs[r]:displs[r] + ny_local[r]], displs[r], flags=lbm._capi.FLAG_ONE_STEP) for r in range(size)]
+        for q in parts:
+            q.bind_halo_tensors(dev)
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(dev)
+    st = tstream.cuda_stream
+    with torch.cuda.stream(tstream):
+        if kstep:
+            for q in parts:
+                q.macro_prepare(steps, st)
+            done = 0
+            while done < steps:
+                for r, q in enumerate(parts):
+                    q.macro_receive_from(parts[(r - 1) % size], lbm.NORTH, st)
+                    q.macro_receive_from(parts[(r + 1) % size], lbm.SOUTH, st)
+                for q in parts:
+                    q.macro_interior(st)
+                    q.macro_edge(st)
+                for q in parts:
+                    q.macro_finish(st)
+                done += K
+        else:
+            for q in parts:
+                q.step_prepare(steps, st)
+            for _ in range(steps):
+                for r, q in enumerate(parts):          # each partition's outgoing rows into its neighbours' incoming buffers
+                    south, north = parts[(r - 1) % size], parts[(r + 1) % size]
+                    south.halo_recv(lbm.NORTH).copy_(q.halo_send(lbm.SOUTH), non_blocking=True)
+                    north.halo_recv(lbm.SOUTH).copy_(q.halo_send(lbm.NORTH), non_blocking=True)
+                for q in parts:
+                    q.step_interior(st)
+                    q.step_boundary(st)
+                    q.step_finish(st)
+        sums = sum(q.step_collect(steps, st) for q in parts)
+    tstream.synchronize()
+    cells = np.concatenate([q.get_cells() for q in parts], axis=0).view(np.uint32).copy()
+    for q in parts:
+        q.close()
+    return cells, (sums * np.float64(np.float32(1.0) / np.float32(free))).astype(np.float32)
+
+
 bad = 0
 for case in range(a.cases):
-    kind = rng.choice(["multi", "tile", "ring"])
+    kind = rng.choice(["multi", "tile", "ring", "parts", "parts1"])
     if kind == "tile":
         T = int(rng.choice([8, 16]))
         nx, ny = T * int(rng.integers(1, 20)), T * int(rng.integers(1, 20))
@@ -34,7 +91,7 @@ for case in range(a.cases):
         nx = 2 * int(rng.integers(64, 400)) if rng.random() < 0.7 else 64 * int(rng.integers(2, 12))
         ny = int(rng.integers(32, 300))
         K = int(rng.integers(1, 5))
-        env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind == "ring" else K)}
+        env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K)}
     steps = int(rng.integers(1, 40))
     dens = float(rng.choice([0.0, 0.002, 0.05, 0.3]))
     p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])), float(rng.choice([0.7, 1.3, 1.85, 1.97])))
@@ -45,6 +102,33 @@ for case in range(a.cases):
         obst[ny - 2, :] = 1
     if obst.all():
         obst[1, 1] = 0
+    if kind in ("parts", "parts1"):
+        size = int(rng.integers(2, 6))
+        if kind == "parts" and ny < 32 * size + 3:
+            ny = 32 * size + int(rng.integers(3, 40))
+            obst = (rng.random((ny, nx)) < dens).astype(np.int32)
+            p = lbm.Params(nx, ny, steps, 4, p.density, p.accel, p.omega)
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        cells, av = run_partitions(p, obst, size, steps, kind == "parts")
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
+        s1 = lbm.Simulation(p, obst)
+        av1 = s1.run(steps)
+        c1 = s1.local_cells().view(np.uint32).copy()
+        s1.close()
+        if cells is None:
+            continue
+        same = np.array_equal(cells, c1)
+        avd = float(np.max(np.abs(av - av1) / np.maximum(np.abs(av1), 1e-30)))
+        if not same or avd > 1e-6:
+            bad += 1
+            print(f"MISMATCH case {case}: {kind} x{size} {nx}x{ny} steps {steps} env {env} dens {dens} cells_same={same} av_rel={avd:.2e}", flush=True)
+        elif case % 25 == 0:
+            print(f"case {case}: {kind} x{size} {nx}x{ny} steps {steps} ok", flush=True)
+        continue
     res = []
     for variant in ("fast", "one-step"):
         for k in KNOBS:
