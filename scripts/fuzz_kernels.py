@@ -18,6 +18,7 @@ import mpilattice_boltzmann_amd as lbm  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=300)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--scale", type=int, default=1, help="multiplies the upper bounds of the random grid sizes")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K"]
@@ -88,8 +89,8 @@ for case in range(a.cases):
             ny = T * 2
         env = {"LBM_TUNE_TILE_MAX": str(1 << 30), "LBM_TUNE_TILE_GEOM": str(T * 10 + int(rng.choice([4, 8]))), "LBM_TUNE_MULTI_K": "0"}
     else:
-        nx = 2 * int(rng.integers(64, 400)) if rng.random() < 0.7 else 64 * int(rng.integers(2, 12))
-        ny = int(rng.integers(32, 300))
+        nx = 2 * int(rng.integers(64, 400 * a.scale)) if rng.random() < 0.7 else 64 * int(rng.integers(2, 12 * a.scale))
+        ny = int(rng.integers(32, 300 * a.scale))
         K = int(rng.integers(1, 5))
         env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K)}
     steps = int(rng.integers(1, 40))
