@@ -15,15 +15,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mpilattice_boltzmann_amd as lbm  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--cases", type=int, default=300)
-ap.add_argument("--seed", type=int, default=1)
-ap.add_argument("--scale", type=int, default=1, help="multiplies the upper bounds of the random grid sizes")
-a = ap.parse_args()
-rng = np.random.default_rng(a.seed)
-KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K"]
-
-
 def run_partitions(p, obst, size, steps, kstep):
     """`size` row partitions of one grid on one GPU, exchanged by device copies in the order of the step loops."""
     import torch
@@ -79,79 +70,104 @@ def run_partitions(p, obst, size, steps, kstep):
     return cells, (sums * np.float64(np.float32(1.0) / np.float32(free))).astype(np.float32)
 
 
-bad = 0
-for case in range(a.cases):
-    kind = rng.choice(["multi", "tile", "ring", "parts", "parts1"])
-    if kind == "tile":
-        T = int(rng.choice([8, 16]))
-        nx, ny = T * int(rng.integers(1, 20)), T * int(rng.integers(1, 20))
-        if ny < 3:
-            ny = T * 2
-        env = {"LBM_TUNE_TILE_MAX": str(1 << 30), "LBM_TUNE_TILE_GEOM": str(T * 10 + int(rng.choice([4, 8]))), "LBM_TUNE_MULTI_K": "0"}
-    else:
-        nx = 2 * int(rng.integers(64, 400 * a.scale)) if rng.random() < 0.7 else 64 * int(rng.integers(2, 12 * a.scale))
-        ny = int(rng.integers(32, 300 * a.scale))
-        K = int(rng.integers(1, 5))
-        env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K)}
-    steps = int(rng.integers(1, 40))
-    dens = float(rng.choice([0.0, 0.002, 0.05, 0.3]))
-    p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])), float(rng.choice([0.7, 1.3, 1.85, 1.97])))
-    obst = (rng.random((ny, nx)) < dens).astype(np.int32)
-    if rng.random() < 0.5:
-        obst[0, :] = obst[-1, :] = 1
-    if rng.random() < 0.2:
-        obst[ny - 2, :] = 1
-    if obst.all():
-        obst[1, 1] = 0
-    if kind in ("parts", "parts1"):
-        size = int(rng.integers(2, 6))
-        if kind == "parts" and ny < 32 * size + 3:
-            ny = 32 * size + int(rng.integers(3, 40))
-            obst = (rng.random((ny, nx)) < dens).astype(np.int32)
-            p = lbm.Params(nx, ny, steps, 4, p.density, p.accel, p.omega)
-        for k in KNOBS:
+KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K"]
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=1, help="multiplies the upper bounds of the random grid sizes")
+    a = ap.parse_args(argv)
+    saved = {k: os.environ.get(k) for k in KNOBS}          # the cases set these; put the caller's values back at the end
+    try:
+        return fuzz(a)
+    finally:
+        for k, v in saved.items():
             os.environ.pop(k, None)
-        os.environ.update(env)
-        cells, av = run_partitions(p, obst, size, steps, kind == "parts")
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
-        s1 = lbm.Simulation(p, obst)
-        av1 = s1.run(steps)
-        c1 = s1.local_cells().view(np.uint32).copy()
-        s1.close()
-        if cells is None:
+            if v is not None:
+                os.environ[k] = v
+
+
+def fuzz(a) -> int:
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+    for case in range(a.cases):
+        kind = rng.choice(["multi", "tile", "ring", "parts", "parts1"])
+        if kind == "tile":
+            T = int(rng.choice([8, 16]))
+            nx, ny = T * int(rng.integers(1, 20)), T * int(rng.integers(1, 20))
+            if ny < 3:
+                ny = T * 2
+            env = {"LBM_TUNE_TILE_MAX": str(1 << 30), "LBM_TUNE_TILE_GEOM": str(T * 10 + int(rng.choice([4, 8]))), "LBM_TUNE_MULTI_K": "0"}
+        else:
+            nx = 2 * int(rng.integers(64, 400 * a.scale)) if rng.random() < 0.7 else 64 * int(rng.integers(2, 12 * a.scale))
+            ny = int(rng.integers(32, 300 * a.scale))
+            K = int(rng.integers(1, 5))
+            env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K)}
+        steps = int(rng.integers(1, 40))
+        dens = float(rng.choice([0.0, 0.002, 0.05, 0.3]))
+        p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])), float(rng.choice([0.7, 1.3, 1.85, 1.97])))
+        obst = (rng.random((ny, nx)) < dens).astype(np.int32)
+        if rng.random() < 0.5:
+            obst[0, :] = obst[-1, :] = 1
+        if rng.random() < 0.2:
+            obst[ny - 2, :] = 1
+        if obst.all():
+            obst[1, 1] = 0
+        if kind in ("parts", "parts1"):
+            size = int(rng.integers(2, 6))
+            if kind == "parts" and ny < 32 * size + 3:
+                ny = 32 * size + int(rng.integers(3, 40))
+                obst = (rng.random((ny, nx)) < dens).astype(np.int32)
+                p = lbm.Params(nx, ny, steps, 4, p.density, p.accel, p.omega)
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            cells, av = run_partitions(p, obst, size, steps, kind == "parts")
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
+            s1 = lbm.Simulation(p, obst)
+            av1 = s1.run(steps)
+            c1 = s1.local_cells().view(np.uint32).copy()
+            s1.close()
+            if cells is None:
+                continue
+            same = np.array_equal(cells, c1)
+            avd = float(np.max(np.abs(av - av1) / np.maximum(np.abs(av1), 1e-30)))
+            if not same or avd > 1e-6:
+                bad += 1
+                print(f"MISMATCH case {case}: {kind} x{size} {nx}x{ny} steps {steps} env {env} dens {dens} cells_same={same} av_rel={avd:.2e}", flush=True)
+            elif case % 25 == 0:
+                print(f"case {case}: {kind} x{size} {nx}x{ny} steps {steps} ok", flush=True)
             continue
-        same = np.array_equal(cells, c1)
-        avd = float(np.max(np.abs(av - av1) / np.maximum(np.abs(av1), 1e-30)))
+        res = []
+        for variant in ("fast", "one-step"):
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            flags, kw = 0, {}
+            if variant == "fast":
+                os.environ.update(env)
+                if kind == "ring":
+                    flags, kw = lbm._capi.FLAG_FORCE_HALO, {"exchange": "rccl"}
+            else:
+                os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
+            s = lbm.Simulation(p, obst, flags=flags, **kw)
+            desc = s.partition.describe()["kernel"] if variant == "fast" else None
+            av = np.concatenate([s.run(steps // 2), s.run(steps - steps // 2)]) if steps > 1 else s.run(steps)
+            res.append((s.local_cells().view(np.uint32).copy(), av, desc))
+            s.close()
+        same = np.array_equal(res[0][0], res[1][0])
+        avd = float(np.max(np.abs(res[0][1] - res[1][1]) / np.maximum(np.abs(res[1][1]), 1e-30)))
         if not same or avd > 1e-6:
             bad += 1
-            print(f"MISMATCH case {case}: {kind} x{size} {nx}x{ny} steps {steps} env {env} dens {dens} cells_same={same} av_rel={avd:.2e}", flush=True)
+            print(f"MISMATCH case {case}: {kind} {nx}x{ny} steps {steps} env {env} dens {dens} kernel {res[0][2]} cells_same={same} av_rel={avd:.2e}", flush=True)
         elif case % 25 == 0:
-            print(f"case {case}: {kind} x{size} {nx}x{ny} steps {steps} ok", flush=True)
-        continue
-    res = []
-    for variant in ("fast", "one-step"):
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        flags, kw = 0, {}
-        if variant == "fast":
-            os.environ.update(env)
-            if kind == "ring":
-                flags, kw = lbm._capi.FLAG_FORCE_HALO, {"exchange": "rccl"}
-        else:
-            os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
-        s = lbm.Simulation(p, obst, flags=flags, **kw)
-        desc = s.partition.describe()["kernel"] if variant == "fast" else None
-        av = np.concatenate([s.run(steps // 2), s.run(steps - steps // 2)]) if steps > 1 else s.run(steps)
-        res.append((s.local_cells().view(np.uint32).copy(), av, desc))
-        s.close()
-    same = np.array_equal(res[0][0], res[1][0])
-    avd = float(np.max(np.abs(res[0][1] - res[1][1]) / np.maximum(np.abs(res[1][1]), 1e-30)))
-    if not same or avd > 1e-6:
-        bad += 1
-        print(f"MISMATCH case {case}: {kind} {nx}x{ny} steps {steps} env {env} dens {dens} kernel {res[0][2]} cells_same={same} av_rel={avd:.2e}", flush=True)
-    elif case % 25 == 0:
-        print(f"case {case}: {kind} {nx}x{ny} steps {steps} {res[0][2]} ok", flush=True)
-print(f"{a.cases} cases, {bad} mismatches")
-sys.exit(1 if bad else 0)
+            print(f"case {case}: {kind} {nx}x{ny} steps {steps} {res[0][2]} ok", flush=True)
+    print(f"{a.cases} cases, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

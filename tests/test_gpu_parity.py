@@ -697,6 +697,18 @@ def test_k_step_partitions_with_rows_the_tile_does_not_divide(lbm, oracle, monke
         part.close()
 
 
+def test_randomised_kernel_cross_check(lbm):
+    """scripts/fuzz_kernels.py with a fixed seed: random shapes, decks, K and tile geometries through the
+    multi / tile kernels, the 1-rank K-step ring and in-process K-step / one-step partitions, each against
+    the one-step kernel on the same deck, bit for bit."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_kernels", os.path.join(ROOT, "scripts", "fuzz_kernels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--cases", "80", "--seed", "11"]) == 0
+
+
 @pytest.mark.parametrize("K", [2, 3, 4])
 @pytest.mark.parametrize("nx,ny", [(206, 142), (130, 37), (650, 62)])
 def test_k_step_ring_message_sizes(lbm, oracle, monkeypatch, nx, ny, K):
