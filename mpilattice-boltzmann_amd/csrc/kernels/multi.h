@@ -106,7 +106,6 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int x0 = tx * kMTX;
   const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
-  const size_t ps = a.ps;
   const int nx = a.nx;
   const int rows_storage = a.rows_owned + 2 * a.ghost;
   const int ksteps = FULL ? K : a.ksteps;
@@ -219,8 +218,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
       const int ry = tid / wp, rp = tid - ry * wp;
       const int fx = EX - ex + 2 * rp;
-#pragma unroll
-      for (int r0 = 0; r0 < rows; r0 += rpp) {
+      for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count in FULL launches: unrolled)
         f2 outs[9];
         int slot = -1;
         const bool in_region = ry < rpp && r0 + ry < rows;
