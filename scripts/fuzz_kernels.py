@@ -70,7 +70,7 @@ def run_partitions(p, obst, size, steps, kstep):
     return cells, (sums * np.float64(np.float32(1.0) / np.float32(free))).astype(np.float32)
 
 
-KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K"]
+KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K", "LBM_TUNE_NARROW_MAX"]
 
 
 def main(argv=None) -> int:
@@ -93,8 +93,22 @@ def fuzz(a) -> int:
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        kind = rng.choice(["multi", "tile", "ring", "parts", "parts1"])
-        if kind == "tile":
+        kind = rng.choice(["multi", "tile", "ring", "parts", "parts1", "forms"])
+        flags_fast = 0
+        if kind == "forms":
+            # the one-step kernels among themselves: one cell per lane / four cells per lane / LDS-staged, with and
+            # without non-temporal stores, any nx (odd too) and ny >= 3
+            nx, ny = int(rng.integers(1, 300)), int(rng.integers(3, 120))
+            form = rng.choice(["narrow", "vector", "lds", "nt", "no_nt"])
+            env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": "0"}
+            if form == "narrow":
+                env["LBM_TUNE_NARROW_MAX"] = str(1 << 30)
+            elif form == "vector":
+                env["LBM_TUNE_NARROW_MAX"] = "0"
+            else:
+                env["LBM_TUNE_NARROW_MAX"] = "0"
+                flags_fast = {"lds": lbm._capi.FLAG_KERNEL_LDS, "nt": lbm._capi.FLAG_NT_STORES, "no_nt": lbm._capi.FLAG_NO_NT_STORES}[form]
+        elif kind == "tile":
             T = int(rng.choice([8, 16]))
             nx, ny = T * int(rng.integers(1, 20)), T * int(rng.integers(1, 20))
             if ny < 3:
@@ -149,6 +163,7 @@ def fuzz(a) -> int:
             flags, kw = 0, {}
             if variant == "fast":
                 os.environ.update(env)
+                flags = flags_fast
                 if kind == "ring":
                     flags, kw = lbm._capi.FLAG_FORCE_HALO, {"exchange": "rccl"}
             else:
