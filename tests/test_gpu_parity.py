@@ -697,6 +697,32 @@ def test_k_step_partitions_with_rows_the_tile_does_not_divide(lbm, oracle, monke
         part.close()
 
 
+def test_randomised_decks_against_the_oracle(lbm, oracle, monkeypatch):
+    """Random shapes (odd nx too), parameters and obstacle densities through the library's default kernel
+    choice, against the oracle: the anchor that scripts/fuzz_kernels.py's GPU-vs-GPU cross-check hangs on."""
+    rng = np.random.default_rng(2026)
+    for case in range(60):
+        big = case % 6 == 0
+        nx = int(rng.integers(128, 700)) & ~1 if big else int(rng.integers(1, 200))
+        ny = int(rng.integers(32, 200)) if big else int(rng.integers(3, 90))
+        steps = int(rng.integers(1, 30))
+        p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])),
+                       float(rng.choice([0.7, 1.3, 1.85, 1.97])))
+        obst = (rng.random((ny, nx)) < float(rng.choice([0.0, 0.01, 0.2]))).astype(np.int32)
+        if rng.random() < 0.3:
+            obst[ny - 2, :] = 1
+        if obst.all():
+            obst[0, 0] = 0
+        s = lbm.Simulation(p, obst)
+        av = s.run(steps)
+        cells = s.local_cells()
+        kernel = s.partition.describe()["kernel"]
+        s.close()
+        ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+        assert np.array_equal(bits(cells), bits(ref_cells)), (case, nx, ny, steps, kernel)
+        assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL, (case, nx, ny, steps, kernel)
+
+
 def test_randomised_kernel_cross_check(lbm):
     """scripts/fuzz_kernels.py with a fixed seed: random shapes, decks, K and tile geometries through the
     multi / tile kernels, the 1-rank K-step ring and in-process K-step / one-step partitions, each against
