@@ -18,8 +18,9 @@ sys.path.insert(0, ROOT)
 
 
 def die(message: str) -> None:
-    """`die()` of the reference (`d2q9-bgk.c:1145-1151`)."""
-    sys.stderr.write(f"Error in {os.path.basename(__file__)}:\n{message}\n")
+    """`die()` of the reference (`d2q9-bgk.c:1145-1151`): "Error at line %d of file %s:\\n%s\\n" on stderr, exit(EXIT_FAILURE)."""
+    caller = sys._getframe(1)
+    sys.stderr.write(f"Error at line {caller.f_lineno} of file {os.path.basename(__file__)}:\n{message}\n")
     sys.stderr.flush()
     sys.exit(1)
 
@@ -34,24 +35,38 @@ def main(argv) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "LBM_FORCE_DEVICE" in os.environ:          # testing aid: several ranks on one device (if the communicator allows it)
         local_rank = int(os.environ["LBM_FORCE_DEVICE"])
-    try:
-        params = lbm.read_params(argv[1])
-        obstacles, _ = lbm.read_obstacles(argv[2], params.nx, params.ny)
-    except lbm.LbmError as e:
-        die(str(e))
+    # rank 0 parses both files (d2q9-bgk.c:772-803, 917-953) before anything touches the GPU; the parameters
+    # travel to the other ranks as the reference's t_param does, the obstacle rows are scattered by Simulation (:966-970)
+    params, obstacles, failure = None, None, None
+    if rank == 0:
+        try:
+            params = lbm.read_params(argv[1])
+            obstacles, _ = lbm.read_obstacles(argv[2], params.nx, params.ny)
+        except lbm.LbmError as e:
+            failure = str(e)
+            if world == 1:
+                die(failure)
     import torch
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = os.environ.get("LBM_DIST_BACKEND", "nccl")         # "gloo": several ranks may share one GPU (testing aid)
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("LBM_DIST_BACKEND", "nccl")     # "gloo": host-staged halos (testing aid)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        box = [params, failure]
+        dist.broadcast_object_list(box, src=0)
+        params, failure = box
+    if failure is not None:
+        if rank == 0:
+            die(failure)
+        return 1
+    # p2p: direct peer-to-peer halo stores (default); rccl: RCCL send/recv; torch: torch.distributed P2P ops
+    exchange = os.environ.get("LBM_EXCHANGE", "auto" if backend == "nccl" or world == 1 else "p2p")
     try:
-        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1,
-                             exchange=os.environ.get("LBM_EXCHANGE", "rccl" if os.environ.get("LBM_DIST_BACKEND", "nccl") == "nccl" else "torch"))
+        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=exchange)
     except lbm.LbmError as e:
         die(str(e))
     if dist is not None:
@@ -62,17 +77,17 @@ def main(argv) -> int:
     torch.cuda.synchronize()
     toc = time.time()                                                      # :397-398
     ru = resource.getrusage(resource.RUSAGE_SELF)
-    cells = sim.gather_cells()                                             # rank 0 gets the whole grid
+    obs = sim.gather_observables()                                         # rank 0 gets (u_x, u_y, u, pressure) of the whole grid
     if rank == 0:
         print("==done==")                                                  # :411-415
-        print("Reynolds number:\t\t%.12E" % sim.reynolds(cells))
+        print("Reynolds number:\t\t%.12E" % sim.reynolds(observables=obs))
         print("Elapsed time:\t\t\t%.6f (s)" % (toc - tic))
         print("Elapsed user CPU time:\t\t%.6f (s)" % ru.ru_utime)
         print("Elapsed system CPU time:\t%.6f (s)" % ru.ru_stime)
         mlups = params.nx * params.ny * params.max_iters / (toc - tic) / 1e6
-        print("MLUPS:\t\t\t\t%.1f (%d GPU%s)" % (mlups, world, "" if world == 1 else "s"))
+        print("MLUPS:\t\t\t\t%.1f (%d GPU%s, %s loop)" % (mlups, world, "" if world == 1 else "s", sim.loop))
         if not os.environ.get("LBM_NO_OUTPUT"):                            # :419-421
-            sim.write_values(av_vels, ".", cells)
+            sim.write_values(av_vels, ".", observables=obs)
     sim.close()
     if dist is not None:
         dist.barrier()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 1
+#define LBM_ABI_VERSION 2
 #define LBM_NSPEEDS 9               /* d2q9-bgk.c:62 */
 
 /* Run constants as read from the parameter file: t_param (d2q9-bgk.c:79-90) minus free_cells_inv,
@@ -90,6 +90,31 @@ int lbm_destroy(lbm_ctx* ctx);
 int lbm_create_global(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacles_all,
                       int y0, int ny_local, int device, unsigned flags);
 
+/* ---- one rank of a row-partitioned run: layout decided from GLOBAL quantities ------------------
+ *
+ * lbm_create_global picks K-step mode and K from the partition it is given; ranks of an uneven
+ * decomposition (ny = 190 on 6 ranks: 32,32,32,32,31,31 rows) or ranks straddling the K = 3 / K = 4
+ * size threshold would then disagree about message sizes and exchange cadence.  A multi-rank run
+ * therefore asks lbm_rank_layout: it applies the reference's decomposition (d2q9-bgk.c:834-862) and
+ * derives ONE mode and ONE K for all ranks from nx, ny, nranks and flags alone (every rank eligible:
+ * min rows >= 32, nx a multiple of 64 or even >= 128, LBM_FLAG_ONE_STEP clear; K = 4 when the largest
+ * partition has < 2 M cells, else 3; LBM_TUNE_MACRO_K overrides) — the same answer on every rank by
+ * construction.  macro_k == 0 means one-step mode (lbm_step_*). */
+typedef struct lbm_layout {
+  int y0, ny_local;                 /* rows [y0, y0+ny_local) of the global grid belong to the rank */
+  int macro_k;                      /* K of K-step mode for the whole run, or 0 */
+  int ghost;                        /* obstacle rows to supply below and above the owned rows (= macro_k) */
+} lbm_layout;
+int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, lbm_layout* out);
+
+/* Replaces, for rank `rank` of `nranks`, the allocation + initial state of initialise()
+ * (d2q9-bgk.c:865-911) AND the receiving end of the obstacle scatter (:968-970): obstacle_window holds
+ * (ny_local + 2*ghost) * nx ints — global rows y0-ghost .. y0+ny_local+ghost-1, wrapping periodically —
+ * i.e. only what this rank needs; no rank but the one that parsed the file ever holds the whole map.
+ * With nranks == 1 the context is a self-contained domain unless LBM_FLAG_FORCE_HALO is set. */
+int lbm_create_rank(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacle_window,
+                    int nranks, int rank, int device, unsigned flags);
+
 /* Replaces the whole timestep loop d2q9-bgk.c:315-394 for a self-contained domain
  * (ny_local == ny): n_steps x { accelerate_flow (:442-478); timestep (:493-704); av_vels[tt]
  * (:367); swap (:376-378) }.  av_vels (host, n_steps floats, may be NULL) receives one value per
@@ -100,6 +125,19 @@ int lbm_run(lbm_ctx* ctx, int n_steps, float* av_vels);
 /* Read / overwrite the partition's cells in the reference's AoS layout (ny_local*nx*9 floats). */
 int lbm_get_cells(lbm_ctx* ctx, float* cells_aos);
 int lbm_set_cells(lbm_ctx* ctx, const float* cells_aos);
+
+/* Device-side write_values() arithmetic (d2q9-bgk.c:1076-1111) for this partition's rows: obs receives
+ * ny_local*nx*4 floats, per cell {u_x, u_y, u, pressure} exactly as the reference computes them for a
+ * fluid cell (the obstacle override :1076-1080 is applied by the writer, which has the map).  4 floats
+ * per cell cross PCIe instead of 9, and no second copy of the state is made on the device. */
+int lbm_get_observables(lbm_ctx* ctx, float* obs);
+
+/* 64-bit digest of the populations of the GLOBAL rows [y_begin, y_end) (which must belong to this partition),
+ * computed on the device.  The digest is a wrap-around sum over cells of a hash of (value bits, global cell
+ * index, population index): the digests of disjoint row ranges ADD UP to the digest of their union, whichever
+ * context holds them.  Lets a partitioned run be compared bit for bit with a single-GPU run of the same deck
+ * (or with itself on other hardware) without moving the state: 8 bytes cross PCIe. */
+int lbm_state_checksum(lbm_ctx* ctx, int y_begin, int y_end, unsigned long long* digest);
 
 /* Device-side av_velocity (d2q9-bgk.c:716-751) over this partition's rows: *tot_u = sum over fluid
  * cells of |u|, accumulated in double.  The caller applies free_cells_inv and sums partitions
@@ -164,6 +202,12 @@ int    lbm_macro_edge(lbm_ctx* ctx, void* stream);
 int    lbm_macro_finish(lbm_ctx* ctx, void* stream);
 int    lbm_macro_exchange_local(lbm_ctx* dst, lbm_ctx* src, int dir, void* stream);
 
+/* Fold the per-block sums of the (macro-)step just finished into the per-step totals NOW, on `stream`,
+ * instead of leaving them to block 0 of the next launch: for callers that need this step's total before the
+ * next step starts (a per-step all-reduce, d2q9-bgk.c:367 as the first MPI version of the reference had it).
+ * Call after lbm_step_finish / lbm_macro_finish, once every launch of the step is ordered before `stream`. */
+int    lbm_step_fold(lbm_ctx* ctx, void* stream);
+
 /* After the last lbm_step_finish of a run: this partition's per-step tot_u sums (double, device
  * resident until now) for the n_steps steps since lbm_step_prepare.  The caller reduces them over
  * partitions (the reference's MPI_Reduce, d2q9-bgk.c:396) and scales by free_cells_inv. */
@@ -193,12 +237,17 @@ int lbm_describe(const lbm_ctx* ctx, char* kernel_name, size_t len, long long* c
 /* av_velocity() for `rows` rows of AoS cells, reference order and precision (d2q9-bgk.c:716-751):
  * returns tot_u (float accumulator). */
 float lbm_av_velocity_host(const lbm_params* p, const float* cells_aos, const int* obstacles, int rows);
+/* The same value from lbm_get_observables() output: u_x, u_y are the floats of :732-746, the double
+ * sqrt and the float accumulation (:748) happen here in the reference's cell order. */
+float lbm_av_velocity_obs(const lbm_params* p, const float* obs, const int* obstacles, int rows);
 /* calc_reynolds() given av_velocity()'s value (d2q9-bgk.c:1005-1007). */
 float lbm_reynolds(const lbm_params* p, float av_velocity);
 /* write_values(): final_state.dat rows (d2q9-bgk.c:1054-1120; displ = global y of row 0; append as
  * ranks > 0 do, :1057) and av_vels.dat (:1127-1139). */
 int lbm_write_final_state(const char* path, const lbm_params* p, const float* cells_aos,
                           const int* obstacles, int rows, int displ, int append);
+int lbm_write_final_state_obs(const char* path, const lbm_params* p, const float* obs,
+                              const int* obstacles, int rows, int displ, int append);
 int lbm_write_av_vels(const char* path, const float* av_vels, int n);
 
 #ifdef __cplusplus

@@ -1,0 +1,64 @@
+/*
+ * lbm_d2q9_p2p.h — C ABI of the row-partitioned step loop with DIRECT peer-to-peer halo stores over xGMI
+ * (part of liblbm_d2q9.so: no RCCL, no MPI).
+ *
+ * Replaces, for one rank of a run with one context per GPU, the communication half of the reference's main
+ * loop — the persistent halo requests (d2q9-bgk.c:295-313), MPI_Startall (:326-327), MPI_Waitall (:364) and
+ * the end-of-run MPI_Reduce (:396) — without a communication library on the path:
+ *
+ *   - every rank maps its two ring neighbours' grids (hipIpcOpenMemHandle across processes, plain peer
+ *     access inside one process) and, once per K steps, a small kernel stores its first / last K rows
+ *     straight into the neighbours' ghost rows (system-scope stores over the direct xGMI link), then
+ *     raises an epoch flag in the neighbour's exported window (release, system scope);
+ *   - the consumer's edge launch is preceded on its stream by a one-wave kernel that spins on the two
+ *     flags (acquire, system scope) with a wall-clock bound: a missing peer ends the run with an error
+ *     instead of a hang, and no workgroup ever waits for another workgroup of its own launch;
+ *   - the two grids are the double buffer (rows for macro-step m+1 land in the grid the consumer does not
+ *     read during macro-step m), so the flags only ever travel forward;
+ *   - the end-of-run reduction is an all-gather of the per-step double sums into every rank's window and a
+ *     local sum in rank order: bitwise the same vector on every rank, no collective library.
+ *
+ * Set-up is a two-phase handshake the caller carries by any means (this repo: torch.distributed
+ * all_gather of LBM_P2P_HANDLE_BYTES per rank; the C CLI: an array in its own address space):
+ *     lbm_p2p_create(&t, ctx, nranks, rank);  lbm_p2p_handle(t, my_blob);
+ *     [all-gather the blobs in rank order]
+ *     lbm_p2p_connect(t, all_blobs);          verifies that every rank runs the same K-step layout
+ *     lbm_p2p_run(t, n_steps, tot_u);         any number of times, the same n_steps on every rank
+ *     lbm_p2p_destroy(t);
+ * Contexts must come from lbm_create_rank (or lbm_create_global) and be in K-step mode
+ * (lbm_macro_steps() > 0); ranks of one run call lbm_p2p_run concurrently (one host thread per rank when
+ * several ranks share a process).
+ */
+#ifndef LBM_D2Q9_P2P_H
+#define LBM_D2Q9_P2P_H
+
+#include "lbm_d2q9.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_P2P_HANDLE_BYTES 512
+
+typedef struct lbm_p2p lbm_p2p;     /* opaque: exported window, mapped peers, streams and events of one rank */
+
+int lbm_p2p_create(lbm_p2p** t, lbm_ctx* ctx, int nranks, int rank);
+int lbm_p2p_handle(lbm_p2p* t, void* blob /* LBM_P2P_HANDLE_BYTES */);
+int lbm_p2p_connect(lbm_p2p* t, const void* blobs /* nranks * LBM_P2P_HANDLE_BYTES, rank order */);
+int lbm_p2p_destroy(lbm_p2p* t);
+
+/* n_steps iterations of d2q9-bgk.c:315-378 for this rank, then the reduction of :396: tot_u_per_step (host,
+ * n_steps doubles) receives the GLOBAL per-step sum of |u|, bitwise identical on every rank;
+ * av_vels[tt] = tot_u_per_step[tt] * free_cells_inv (:367).  Returns after the device work has completed;
+ * non-zero if a neighbour's rows did not arrive within the time-out (LBM_P2P_TIMEOUT_MS, default 30 000). */
+int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step);
+
+/* Facts for logs and the measurement harness: how the exported window was allocated ("uncached",
+ * "fine-grained" or "coarse"), how the neighbours are reached ("ipc", "in-process" or "self"), and the
+ * schedule ("edge stream" = edge rows beside the interior launch, or "serial"). */
+int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

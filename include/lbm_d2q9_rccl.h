@@ -33,6 +33,17 @@ int lbm_comm_unique_id(char id[LBM_COMM_ID_BYTES]);
 int lbm_comm_create(lbm_comm** comm, lbm_ctx* ctx, const char id[LBM_COMM_ID_BYTES], int nranks, int rank);
 int lbm_comm_destroy(lbm_comm* comm);
 
+/* Number of ranks of the communicator as RCCL reports it (ncclCommCount): what actually runs, for logs. */
+int lbm_comm_nranks(const lbm_comm* comm);
+
+/* Reduction mode.  0 (default): the reference's final form — per-rank partial sums stay on the device and
+ * ONE all-reduce of the whole per-step vector follows the loop (d2q9-bgk.c:367,396; report.odt §1 measured
+ * 1.13-2.39x from hoisting the reduce out of the loop).  1: one ncclAllReduce per (macro-)step on the compute
+ * stream, the next step ordered behind it — BASELINE.json's north_star wording and the reference's first MPI
+ * version (newprofiles/firstMPI*.out).  Same av_vels either way (same double sums, same rank order inside
+ * RCCL's ring for a given communicator); the mode exists so that its cost can be measured. */
+int lbm_comm_set_step_allreduce(lbm_comm* comm, int on);
+
 /* n_steps iterations of d2q9-bgk.c:315-378 for this rank, then the reduction of :396 as an
  * all-reduce: tot_u_per_step (host, n_steps doubles) receives the GLOBAL per-step sum of |u| on
  * every rank; av_vels[tt] = tot_u_per_step[tt] * free_cells_inv (:367).  Returns after the

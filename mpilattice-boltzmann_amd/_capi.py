@@ -13,7 +13,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NSPEEDS = 9
 
 FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP = 0, 1, 2, 4, 8, 16, 32
@@ -30,6 +30,12 @@ class CParams(C.Structure):
                 ("density", C.c_float), ("accel", C.c_float), ("omega", C.c_float)]
 
 
+class CLayout(C.Structure):
+    """struct lbm_layout."""
+
+    _fields_ = [("y0", C.c_int), ("ny_local", C.c_int), ("macro_k", C.c_int), ("ghost", C.c_int)]
+
+
 _P = C.POINTER
 _ctx = C.c_void_p
 _SIGNATURES = {
@@ -40,10 +46,14 @@ _SIGNATURES = {
     "lbm_decompose": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_create": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_create_global": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "lbm_rank_layout": (C.c_int, [_P(CParams), C.c_int, C.c_int, C.c_uint, _P(CLayout)]),
+    "lbm_create_rank": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_destroy": (C.c_int, [_ctx]),
     "lbm_run": (C.c_int, [_ctx, C.c_int, _P(C.c_float)]),
     "lbm_get_cells": (C.c_int, [_ctx, _P(C.c_float)]),
     "lbm_set_cells": (C.c_int, [_ctx, _P(C.c_float)]),
+    "lbm_get_observables": (C.c_int, [_ctx, _P(C.c_float)]),
+    "lbm_state_checksum": (C.c_int, [_ctx, C.c_int, C.c_int, _P(C.c_ulonglong)]),
     "lbm_av_velocity_sum": (C.c_int, [_ctx, _P(C.c_double)]),
     "lbm_halo_floats": (C.c_size_t, [_ctx]),
     "lbm_halo_send_ptr": (C.c_void_p, [_ctx, C.c_int]),
@@ -66,6 +76,7 @@ _SIGNATURES = {
     "lbm_macro_edge": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_finish": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_exchange_local": (C.c_int, [_ctx, _ctx, C.c_int, C.c_void_p]),
+    "lbm_step_fold": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_step_collect": (C.c_int, [_ctx, C.c_void_p, _P(C.c_double), C.c_int]),
     "lbm_step_sums_device_ptr": (C.c_void_p, [_ctx]),
     "lbm_last_run_kernel_ms": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_int)]),
@@ -73,17 +84,33 @@ _SIGNATURES = {
     "lbm_stream": (C.c_void_p, [_ctx]),
     "lbm_describe": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_longlong), _P(C.c_longlong)]),
     "lbm_av_velocity_host": (C.c_float, [_P(CParams), _P(C.c_float), _P(C.c_int), C.c_int]),
+    "lbm_av_velocity_obs": (C.c_float, [_P(CParams), _P(C.c_float), _P(C.c_int), C.c_int]),
     "lbm_reynolds": (C.c_float, [_P(CParams), C.c_float]),
     "lbm_write_final_state": (C.c_int, [C.c_char_p, _P(CParams), _P(C.c_float), _P(C.c_int), C.c_int, C.c_int, C.c_int]),
+    "lbm_write_final_state_obs": (C.c_int, [C.c_char_p, _P(CParams), _P(C.c_float), _P(C.c_int), C.c_int, C.c_int, C.c_int]),
     "lbm_write_av_vels": (C.c_int, [C.c_char_p, _P(C.c_float), C.c_int]),
 }
 EXPORTS = tuple(_SIGNATURES)
+
+# include/lbm_d2q9_p2p.h (same library)
+P2P_HANDLE_BYTES = 512
+_P2P_SIGNATURES = {
+    "lbm_p2p_create": (C.c_int, [_P(C.c_void_p), _ctx, C.c_int, C.c_int]),
+    "lbm_p2p_handle": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "lbm_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "lbm_p2p_destroy": (C.c_int, [C.c_void_p]),
+    "lbm_p2p_run": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
+    "lbm_p2p_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+}
+P2P_EXPORTS = tuple(_P2P_SIGNATURES)
 
 _RCCL_SIGNATURES = {
     "lbm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "lbm_comm_create": (C.c_int, [_P(C.c_void_p), _ctx, C.c_char_p, C.c_int, C.c_int]),
     "lbm_comm_destroy": (C.c_int, [C.c_void_p]),
     "lbm_comm_run": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
+    "lbm_comm_nranks": (C.c_int, [C.c_void_p]),
+    "lbm_comm_set_step_allreduce": (C.c_int, [C.c_void_p, C.c_int]),
 }
 RCCL_EXPORTS = tuple(_RCCL_SIGNATURES)
 COMM_ID_BYTES = 128
@@ -122,7 +149,7 @@ def load_library() -> C.CDLL:
     except ImportError:
         pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in {**_SIGNATURES, **_P2P_SIGNATURES}.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
     if lib.lbm_abi_version() != ABI_VERSION:

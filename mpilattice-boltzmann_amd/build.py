@@ -40,7 +40,8 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
     hipcc = _hipcc()
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
-    headers = [os.path.join(ROOT, "include", "lbm_d2q9.h"), os.path.join(CSRC, "lbm_internal.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(ROOT, "include", "lbm_d2q9.h"), os.path.join(ROOT, "include", "lbm_d2q9_p2p.h"),
+               os.path.join(CSRC, "lbm_internal.h"), os.path.join(CSRC, "lbm_p2p_impl.h"), os.path.abspath(__file__)]
     headers += sorted(glob.glob(os.path.join(CSRC, "kernels", "*.h")))       # device code, included by lbm_kernels.hip
     lib_src = [os.path.join(CSRC, "lbm_kernels.hip"), os.path.join(CSRC, "lbm_host.cpp")]
     if force or _stale(LIB, lib_src + headers):

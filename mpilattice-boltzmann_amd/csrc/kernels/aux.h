@@ -5,7 +5,24 @@
 
 namespace {
 
-// Folds the last step's partials after the loop.
+// Folds the last launch's partials after the loop (every other launch's are folded by block 0 of the
+// launch that follows it).  One block per step vector when the vectors are short; long vectors (8192x8192:
+// 3 x 65 536 per-tile sums, which took one block 102 us) go through lbm_fold_slices_kernel first:
+// kFoldSlices blocks per vector, then this kernel over the kFoldSlices slice sums.  Fixed order, no atomics.
+constexpr int kFoldSlices = 64;
+
+__global__ void __launch_bounds__(kBlock) lbm_fold_slices_kernel(const double* partials, int n, double* slice_sums)
+{
+  __shared__ double red[kBlock / 64];
+  const int v = blockIdx.y, b = blockIdx.x;
+  const int per = (n + kFoldSlices - 1) / kFoldSlices;
+  const int lo = b * per, hi = min(n, lo + per);
+  double s = 0.0;
+  for (int i = lo + static_cast<int>(threadIdx.x); i < hi; i += kBlock) s += partials[static_cast<size_t>(v) * n + i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) slice_sums[v * kFoldSlices + b] = s;
+}
+
 __global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, int nvecs, double* sums, int* counter)
 {
   __shared__ double red[kBlock / 64];
@@ -95,12 +112,15 @@ __global__ void lbm_macro_pack_kernel(const float* grid, float* buf, size_t ps, 
 }
 
 // av_velocity (d2q9-bgk.c:716-751): per-cell float arithmetic as the reference, double accumulation.
-__global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t ncells, double* partials)
+// Cell c of the owned rows is bit c + bit0 of the obstacle bitfield (K-step partitions: bit0 = ghost*nx,
+// any value, not only multiples of 32).
+__global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t bit0, size_t ncells, double* partials)
 {
   __shared__ double red[kBlock / 64];
   double acc = 0.0;
   for (size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; c < ncells; c += static_cast<size_t>(gridDim.x) * kBlock) {
-    if ((mask[c >> 5] >> (c & 31)) & 1u) continue;
+    const size_t b = c + bit0;
+    if ((mask[b >> 5] >> (b & 31)) & 1u) continue;
     float f[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) f[k] = grid[k * ps + c];
@@ -113,6 +133,58 @@ __global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* gr
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// write_values()' per-cell arithmetic for a fluid cell (d2q9-bgk.c:1084-1111) on cells [0, n) of `grid`
+// (already offset to the first cell wanted): obs[4c..4c+3] = {u_x, u_y, u, pressure}.  Same float
+// operations in the same order as the reference (division and sqrt correctly rounded), so the values are
+// the bits the host writer computes from the 9 populations.  A NaN produced here from non-NaN inputs
+// (rho = 0) gets the sign x86 gives a generated NaN, which is what the reference's fprintf shows ("-NAN").
+__global__ void __launch_bounds__(kBlock) lbm_observables_kernel(const float* grid, size_t ps, size_t n, float* obs)
+{
+  const size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (c >= n) return;
+  float f[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) f[k] = grid[k * ps + c];
+  float rho = 0.0f;
+  bool nan_in = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { rho += f[k]; nan_in |= (f[k] != f[k]); }         // :1084-1090
+  f4 o;
+  o.x = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;                       // :1093-1099
+  o.y = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;                       // :1101-1107
+  o.z = static_cast<float>(sqrt_of_float((o.x * o.x) + (o.y * o.y)));            // :1109
+  o.w = rho * (1.0f / 3.0f);                                                     // :1111, c_sq of :1040
+  if (!nan_in) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (o[j] != o[j]) o[j] = __uint_as_float(0xFFC00000u);
+  }
+  *reinterpret_cast<f4*>(obs + 4 * c) = o;
+}
+
+// Order-independent 64-bit digest of the populations of `n` cells starting at local cell c0 (all 9 planes):
+// sum over (cell, k) of mix(bits(f) ^ golden * global_index), wrap-around.  Additive over disjoint row ranges,
+// so the digests of the ranks of a partitioned run add up to the digest of the whole grid; equal states give
+// equal digests whatever the partitioning, and a single differing bit changes it (with probability 1 - 2^-64).
+__global__ void __launch_bounds__(kBlock) lbm_checksum_kernel(const float* grid, size_t ps, size_t n, unsigned long long global_cell0,
+                                                              unsigned long long* out)
+{
+  unsigned long long h = 0;
+  for (size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; c < n; c += static_cast<size_t>(gridDim.x) * kBlock) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const unsigned long long idx = (global_cell0 + c) * 9ull + static_cast<unsigned long long>(k);
+      unsigned long long z = static_cast<unsigned long long>(__float_as_uint(grid[k * ps + c])) ^ (idx * 0x9E3779B97F4A7C15ull);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      h += z ^ (z >> 31);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
 }  // namespace

@@ -51,7 +51,6 @@ struct MultiArgs {
   int tiles_x;
   int tile_begin, tile_count, tile_begin2, tile_count2;   // tile ranges of this launch (second may be empty)
   int ntiles_total;            // stride of partials_out
-  int ksteps;                  // 1..K steps in this launch
   int xcd_remap;               // tile order: contiguous eighth per XCD (needs (tile_count+tile_count2) % 8 == 0)
   float omega, accel_w1, accel_w2;
   int accel_row;               // GLOBAL row ny-2
@@ -63,7 +62,10 @@ struct MultiArgs {
   int* counter;
 };
 
-template <int K, bool FULL>   // FULL: this launch does exactly K steps (all region sizes are compile-time constants)
+// One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
+// constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
+// lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
+template <int K>
 __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K>;
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
   const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
   const int nx = a.nx;
   const int rows_storage = a.rows_owned + 2 * a.ghost;
-  const int ksteps = FULL ? K : a.ksteps;
+  constexpr int ksteps = K;
   double acc[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) acc[i] = 0.0;
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
       const int ry = tid / wp, rp = tid - ry * wp;
       const int fx = EX - ex + 2 * rp;
-      for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count in FULL launches: unrolled)
+      for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count: unrolled)
         f2 outs[9];
         int slot = -1;
         const bool in_region = ry < rpp && r0 + ry < rows;
@@ -262,13 +264,9 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       }
       if (!last) __syncthreads();
     };
-    if constexpr (FULL) {          // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
+    // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
 #pragma unroll
-      for (int j = 2; j <= K; ++j) in_lds_substep(j);
-    } else {
-#pragma unroll 1
-      for (int j = 2; j <= ksteps; ++j) in_lds_substep(j);
-    }
+    for (int j = 2; j <= K; ++j) in_lds_substep(j);
   }
 
   // per-step sums over the owned cells of this tile

@@ -1,0 +1,128 @@
+// p2p.h — kernels of the peer-to-peer halo transport (include/lbm_d2q9_p2p.h): push rows into a neighbour's
+// ghost rows, raise / await epoch flags, all-gather + fold of the per-step sums.
+// Part of the single translation unit lbm_kernels.hip (device code of liblbm_d2q9.so, gfx950 only).
+//
+// Memory-model notes (gfx950): a peer GPU's memory is reached over xGMI through this GPU's L2, so what is
+// meant for the peer is written with system-scope stores (write-through, `sc0 sc1`) and followed by a
+// system-scope release fence before the flag; flags live in an uncached window and are read / written with
+// system-scope atomics; the consumer's data loads happen in a LATER kernel of its stream (kernel boundaries
+// invalidate the non-coherent caches, as they must between any two launches that hand data across XCDs).
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct P2PWindowHeader {                 // start of every rank's exported window (uncached device memory)
+  unsigned long long halo_flag[2];       // [0]: epoch of the rows my SOUTH neighbour pushed into my bottom ghost rows; [1]: NORTH
+  unsigned long long halo_parity[2];     // the pusher's grid parity for that epoch (lock-step check)
+  unsigned long long reduce_flag[64];    // [r]: rank r's sums of reduce round N are in my slot r
+};
+constexpr size_t kP2PHeaderBytes = 4096;
+static_assert(sizeof(P2PWindowHeader) <= kP2PHeaderBytes, "window header");
+
+__device__ __forceinline__ void store_system(float* p, f2 v)
+{
+  static_assert(sizeof(f2) == sizeof(unsigned long long), "f2 is 8 bytes");
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct P2PPushArgs {
+  const float* src;                      // my grid (plane 0, storage row 0)
+  size_t ps;                             // my plane stride
+  float* dst[2];                         // [0]: south neighbour's grid, plane 0, first of its TOP ghost rows; [1]: north neighbour's, row 0
+  size_t dst_ps[2];                      // their plane strides
+  size_t src_row[2];                     // my storage row where direction d's K rows start
+  int nfloats;                           // K * nx
+  unsigned long long* flag[2];           // [0]: south neighbour's halo_flag[1] (rows arrive from ITS north); [1]: north neighbour's halo_flag[0]
+  unsigned long long* parity_word[2];
+  unsigned long long epoch, parity;
+  unsigned int* done;                    // block-done counter (my device memory), zero between launches
+};
+
+// My first K owned rows -> the south neighbour's top ghost rows, my last K owned rows -> the north
+// neighbour's bottom ghost rows (all 9 planes), then the two epoch flags, raised by the last block to
+// finish.  grid = (ceil(nfloats/2/256), 9, 2).
+__global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, int nx)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // float2 index within one plane's K rows (nx even)
+  const int plane = blockIdx.y, dir = blockIdx.z;
+  if (i * 2 < a.nfloats) {
+    const f2 v = *reinterpret_cast<const f2*>(a.src + plane * a.ps + a.src_row[dir] * nx + static_cast<size_t>(i) * 2);
+    store_system(a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * 2, v);
+  }
+  __threadfence_system();                                      // this lane's rows are on their way before ...
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == total - 1) {                                   // ... the last block raises the flags
+      __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int d = 0; d < 2; ++d) {
+        __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// One wave: wait until every one of `nflags` flag words has reached `epoch` (acquire, system scope), at
+// most `timeout_ticks` of the 100 MHz wall clock; on time-out set *err (host-visible) to 1 + the index of
+// the missing flag.  With *err already set the kernel returns at once, so a failed run drains quickly.
+// parity_words (may be null): the pushers' grid parity must equal `parity` (ranks run in lock step).
+__global__ void __launch_bounds__(64) lbm_p2p_wait_kernel(const unsigned long long* flags, const unsigned long long* parity_words, int nflags,
+                                                           unsigned long long epoch, unsigned long long parity, long long timeout_ticks, int* err)
+{
+  if (threadIdx.x != 0) return;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  const long long t0 = wall_clock64();
+  for (int f = 0; f < nflags; ++f) {
+    while (__hip_atomic_load(flags + f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(err, 1 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (parity_words && __hip_atomic_load(parity_words + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
+      __hip_atomic_store(err, 100 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+  __threadfence_system();
+}
+
+// End-of-run reduction, step 1: my per-step sums into slot `my_rank` of EVERY rank's window (mine included).
+// grid = (ceil(n/256), nranks); slots[r] = rank r's slot for me.
+__global__ void __launch_bounds__(256) lbm_p2p_gather_kernel(const double* sums, int n, double* const* slots)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slots[blockIdx.y] + i), __builtin_bit_cast(unsigned long long, sums[i]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+}
+
+// step 2 (a later kernel of the same stream, so the stores above have been issued and fenced): raise my flag
+// in every rank's window.
+__global__ void __launch_bounds__(64) lbm_p2p_reduce_signal_kernel(unsigned long long* const* flags, int nranks, unsigned long long round)
+{
+  __threadfence_system();
+  if (static_cast<int>(threadIdx.x) < nranks) __hip_atomic_store(flags[threadIdx.x], round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// step 3 (after lbm_p2p_wait_kernel on my nranks reduce flags): out[t] = sum over ranks, in rank order, of
+// slot r's entry t — the reference's MPI_Reduce(MPI_SUM) (d2q9-bgk.c:396), the same bits on every rank.
+__global__ void __launch_bounds__(256) lbm_p2p_fold_kernel(const double* slots, size_t slot_stride, int nranks, int n, double* out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int r = 0; r < nranks; ++r)
+    s += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slots + r * slot_stride + i), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_SYSTEM));
+  out[i] = s;
+}
+
+}  // namespace

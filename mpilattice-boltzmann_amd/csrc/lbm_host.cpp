@@ -121,6 +121,19 @@ float lbm_av_velocity_host(const lbm_params* p, const float* cells, const int* o
   return tot_u;
 }
 
+// The same sum from device-computed u_x, u_y (lbm_get_observables): :748 in the reference's cell order.
+float lbm_av_velocity_obs(const lbm_params* p, const float* obs, const int* obstacles, int rows)
+{
+  float tot_u = 0.0f;
+  const size_t n = static_cast<size_t>(rows) * static_cast<size_t>(p->nx);
+  for (size_t c = 0; c < n; ++c) {
+    if (obstacles[c]) continue;                                                 // :721
+    const float ux = obs[4 * c], uy = obs[4 * c + 1];
+    tot_u += std::sqrt(static_cast<double>((ux * ux) + (uy * uy)));            // :748
+  }
+  return tot_u;
+}
+
 // d2q9-bgk.c:1005-1007.
 float lbm_reynolds(const lbm_params* p, float av_velocity)
 {
@@ -132,8 +145,12 @@ float lbm_reynolds(const lbm_params* p, float av_velocity)
 // (:1115), produced by std::to_chars (shortest-correct scientific formatting at precision 12 is what
 // glibc prints too) over row blocks formatted in parallel and written in order: at 8192x8192 the file
 // is 5.8 GB of text and formatting it dominates the run if done through stdio.
-int lbm_write_final_state(const char* path, const lbm_params* p, const float* cells, const int* obstacles,
-                          int rows, int displ, int append)
+// `fluid(c, u_x, u_y, u, pressure)` supplies the four values of a non-obstacle cell (:1084-1111).
+}  // extern "C"
+
+namespace {
+template <typename Fluid>
+int write_final_state_impl(const char* path, const lbm_params* p, const int* obstacles, int rows, int displ, int append, Fluid fluid)
 {
   std::FILE* fp = std::fopen(path, append ? "a" : "w");                        // :1054-1057
   if (!fp) { set_error("could not open file output file"); return 1; }         // :1061
@@ -164,13 +181,7 @@ int lbm_write_final_state(const char* path, const lbm_params* p, const float* ce
           u_x = u_y = u = 0.0f;
           pressure = obstacle_pressure;
         } else {
-          const float* f = cells + c * LBM_NSPEEDS;
-          float rho = 0.0f;
-          for (int k = 0; k < LBM_NSPEEDS; ++k) rho += f[k];                   // :1084-1090
-          u_x = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;             // :1093-1099
-          u_y = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;             // :1101-1107
-          u = static_cast<float>(std::sqrt(static_cast<double>((u_x * u_x) + (u_y * u_y))));   // :1109
-          pressure = rho * c_sq;                                               // :1111
+          fluid(c, u_x, u_y, u, pressure);
         }
         char* q = line;                                                        // :1115
         q = put_int(q, x); *q++ = ' ';
@@ -210,6 +221,36 @@ int lbm_write_final_state(const char* path, const lbm_params* p, const float* ce
   if (std::fclose(fp) != 0) ok = false;
   if (!ok) { set_error("could not write file output file"); return 1; }
   return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int lbm_write_final_state(const char* path, const lbm_params* p, const float* cells, const int* obstacles,
+                          int rows, int displ, int append)
+{
+  if (!path || !p || !cells || !obstacles) { set_error("lbm_write_final_state: null argument"); return 1; }
+  const float c_sq = 1.0f / 3.0f;
+  return write_final_state_impl(path, p, obstacles, rows, displ, append, [=](size_t c, float& u_x, float& u_y, float& u, float& pressure) {
+    const float* f = cells + c * LBM_NSPEEDS;
+    float rho = 0.0f;
+    for (int k = 0; k < LBM_NSPEEDS; ++k) rho += f[k];                       // :1084-1090
+    u_x = (f[1] + f[5] + f[8] - (f[3] + f[6] + f[7])) / rho;                 // :1093-1099
+    u_y = (f[2] + f[5] + f[6] - (f[4] + f[7] + f[8])) / rho;                 // :1101-1107
+    u = static_cast<float>(std::sqrt(static_cast<double>((u_x * u_x) + (u_y * u_y))));   // :1109
+    pressure = rho * c_sq;                                                   // :1111
+  });
+}
+
+// The same file from lbm_get_observables() output: the four values were computed on the device.
+int lbm_write_final_state_obs(const char* path, const lbm_params* p, const float* obs, const int* obstacles,
+                              int rows, int displ, int append)
+{
+  if (!path || !p || !obs || !obstacles) { set_error("lbm_write_final_state_obs: null argument"); return 1; }
+  return write_final_state_impl(path, p, obstacles, rows, displ, append, [=](size_t c, float& u_x, float& u_y, float& u, float& pressure) {
+    const float* o = obs + 4 * c;
+    u_x = o[0]; u_y = o[1]; u = o[2]; pressure = o[3];
+  });
 }
 
 // d2q9-bgk.c:1127-1139.

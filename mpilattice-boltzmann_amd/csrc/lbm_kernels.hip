@@ -41,6 +41,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -51,6 +52,7 @@
 #include "kernels/tile.h"
 #include "kernels/multi.h"
 #include "kernels/aux.h"
+#include "kernels/p2p.h"
 
 namespace {
 
@@ -115,6 +117,7 @@ struct lbm_ctx {
   int partials_cap = 0;
   int n_part_interior = 0, n_part_boundary = 0, n_part_full = 0;
   int iters_full = 1, iters_interior = 1;
+  double* fold_scratch = nullptr;   // kFoldSlices x 8 slice sums of the end-of-run fold (long partial vectors)
   double* sums = nullptr;
   int sums_cap = 0;
   int* counter = nullptr;
@@ -158,7 +161,13 @@ int blocks_for(long long quads, int iters)
   return static_cast<int>((quads + per_block - 1) / per_block);
 }
 
-hipStream_t pick_stream(lbm_ctx* c, void* stream) { return stream ? static_cast<hipStream_t>(stream) : c->stream; }
+// Every entry point that launches or copies goes through here: the launch must happen with the context's
+// device current (a caller driving several GPUs from one thread leaves another one current).
+hipStream_t pick_stream(lbm_ctx* c, void* stream)
+{
+  (void)hipSetDevice(c->device);   // cheap when already current
+  return stream ? static_cast<hipStream_t>(stream) : c->stream;
+}
 
 void drop_graphs(lbm_ctx* c)
 {
@@ -218,9 +227,7 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 template <int K>
 void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a)
 {
-  using G = MultiGeom<K>;
-  if (a.ksteps == K) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
-  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), G::lds_bytes, s>>>(a);
+  lbm_multi_kernel<K><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K>::lds_bytes, s>>>(a);
 }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
@@ -235,7 +242,6 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   a.tiles_x = c->multi_tiles_x;
   a.tile_begin = t0; a.tile_count = n0; a.tile_begin2 = t1; a.tile_count2 = n1;
   a.ntiles_total = c->multi_tiles;
-  a.ksteps = ksteps;
   a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
   a.accel_row = c->p.ny - 2; a.accel_last = accel_last ? 1 : 0;
   a.partials_out = c->partials[c->parity];
@@ -245,7 +251,9 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   const int blocks = n0 + n1;
   // measured on 8192x8192, K=2: 515 us/step with the XCD-contiguous tile order, 549 without
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
-  switch (c->multi_K) {
+  // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
+  // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
+  switch (std::min(ksteps, c->multi_K)) {
     case 1: launch_multi_k<1>(blocks, s, a); break;
     case 2: launch_multi_k<2>(blocks, s, a); break;
     case 3: launch_multi_k<3>(blocks, s, a); break;
@@ -281,6 +289,23 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
   c->ev_launches = 0;
   c->ev_tile_launches = 0;
   HIP_TRY(hipEventRecord(c->ev_begin, s));
+  return 0;
+}
+
+// d2q9-bgk.c:367 for the LAST launch of a run: its per-block sums have no following launch to fold them.
+int fold_last(lbm_ctx* c, hipStream_t s)
+{
+  if (c->n_prev == 0) return 0;          // already folded (lbm_step_fold)
+  const double* part = c->partials[c->parity ^ 1];
+  if (c->n_prev >= 8192) {
+    hipLaunchKernelGGL(lbm_fold_slices_kernel, dim3(kFoldSlices, c->n_prev_vecs), dim3(kBlock), 0, s, part, c->n_prev, c->fold_scratch);
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->fold_scratch, kFoldSlices, c->n_prev_vecs, c->sums, c->counter);
+  } else {
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, part, c->n_prev, c->n_prev_vecs, c->sums, c->counter);
+  }
+  HIP_TRY(hipGetLastError());
+  c->n_prev = 0;
+  c->n_prev_vecs = 1;
   return 0;
 }
 
@@ -325,10 +350,63 @@ int ensure_graph(lbm_ctx* c, hipStream_t s)
 
 }  // namespace
 
-// lbm_create / lbm_create_global.  obstacles_global (ny*nx, may be null) additionally gives the
-// obstacle flags of the rows around the partition, which the K-step kernels need for their ghost rows.
+// Is a row partition of `rows` rows eligible for K-step mode (lbm_multi_kernel with ghost rows) ?
+static bool macro_eligible(const lbm_params* p, int rows, unsigned flags)
+{
+  // the multi kernel addresses a plane with 32-bit byte offsets: < 2^30 storage cells
+  const bool fits_u32 = static_cast<size_t>(p->nx) * (rows + 2 * kMaxMultiSteps) < (size_t(1) << 30);
+  return !(flags & LBM_FLAG_ONE_STEP) && rows >= 2 * kMTY && fits_u32 && (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX));
+}
+
+// K for partitions of at most `max_cells` cells.  Measured on a 1-rank ring with the packed exchange,
+// us/step for K = 2 / 3 / 4 (one-step loop):
+//   8192x4096 rows 243 / 182 / 199   8192x2048 rows 122 / 92.6 / 103   8192x1024 rows 66.2 / 52.5 / 55.9 (116)
+//   1024x128 rows 26.1 / 18.8 / 14.7 (37)
+static int macro_k_for(size_t max_cells)
+{
+  const int by_size = max_cells < (1u << 21) ? 4 : 3;
+  return std::min(std::max(tune_env("LBM_TUNE_MACRO_K", by_size), 0), kMaxMultiSteps);
+}
+
+// Obstacle bitfield of the storage rows: bit i of the linear storage cell index, row r of the storage taken
+// from row_ptr(r).  Word ranges are packed by several host threads (67 M cells at 8192x8192).
+template <typename RowPtr>
+static void pack_obstacle_bits(std::vector<uint32_t>& bits, int rows, int nx, RowPtr row_ptr)
+{
+  const size_t ncells = static_cast<size_t>(rows) * nx, nwords = (ncells + 31) / 32;
+  auto pack = [&](size_t w0, size_t w1) {
+    size_t i = w0 * 32;
+    int r = static_cast<int>(i / nx), x = static_cast<int>(i - static_cast<size_t>(r) * nx);
+    const int* row = r < rows ? row_ptr(r) : nullptr;
+    for (size_t w = w0; w < w1; ++w) {
+      uint32_t v = 0;
+      for (int b = 0; b < 32 && i < ncells; ++b, ++i) {
+        if (row[x]) v |= 1u << b;
+        if (++x == nx) { x = 0; ++r; row = r < rows ? row_ptr(r) : nullptr; }
+      }
+      bits[w] = v;
+    }
+  };
+  unsigned workers = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (nwords < (1u << 16)) workers = 1;
+  if (workers == 1) { pack(0, nwords); return; }
+  std::vector<std::thread> pool;
+  const size_t per = (nwords + workers - 1) / workers;
+  for (unsigned t = 0; t < workers; ++t) {
+    const size_t w0 = std::min(nwords, t * per), w1 = std::min(nwords, w0 + per);
+    if (w0 < w1) pool.emplace_back(pack, w0, w1);
+  }
+  for (std::thread& t : pool) t.join();
+}
+
+// lbm_create / lbm_create_global / lbm_create_rank.  The obstacle flags of the ghost rows that the K-step
+// kernels need come either from obstacles_global (ny*nx, lbm_create_global) or from obstacles_window
+// ((ny_local + 2*forced_k)*nx: the rows around the partition only, lbm_create_rank); both null = no ghost
+// rows possible.  forced_k < 0: K-step mode and K decided from this partition's own shape
+// (lbm_create_global); >= 0: decided by the caller for the whole run (lbm_rank_layout).
 static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows,
-                       const int* obstacles_global, int y0, int ny_local, int device, unsigned flags)
+                       const int* obstacles_global, const int* obstacles_window, int forced_k, int y0, int ny_local,
+                       int device, unsigned flags)
 {
   if (!out || !p || !obstacles_rows) { lbm_internal::set_error("lbm_create: null argument"); return 1; }
   *out = nullptr;
@@ -359,16 +437,17 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->ncells = static_cast<size_t>(p->nx) * ny_local;
   // K-step mode of a row-partitioned run: K ghost rows on each side of the owned rows, refreshed by the
   // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
-  // (the multi kernel addresses a plane with 32-bit byte offsets: < 2^30 storage cells)
   const bool fits_u32 = static_cast<size_t>(p->nx) * (ny_local + 2 * kMaxMultiSteps) < (size_t(1) << 30);
-  if (!self_periodic && obstacles_global && !(flags & LBM_FLAG_ONE_STEP) && ny_local >= 2 * kMTY && fits_u32 &&
-      (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX))) {
-    // measured on a 1-rank ring with the packed exchange, us/step for K = 2 / 3 / 4 (one-step loop):
-    //   8192x4096 rows 243 / 182 / 199   8192x2048 rows 122 / 92.6 / 103   8192x1024 rows 66.2 / 52.5 / 55.9 (116)
-    //   1024x128 rows 26.1 / 18.8 / 14.7 (37)
-    const int by_size = c->ncells < (1u << 21) ? 4 : 3;
-    const int k = tune_env("LBM_TUNE_MACRO_K", by_size);
-    if (k > 0) { c->multi_K = std::min(k, kMaxMultiSteps); c->ghost = c->multi_K; }
+  if (forced_k > 0) {
+    if (self_periodic || !obstacles_window || forced_k > kMaxMultiSteps || !macro_eligible(p, ny_local, flags)) {
+      lbm_internal::set_error("lbm_create_rank: partition cannot run the K-step mode its layout asks for");
+      delete c;
+      return 1;
+    }
+    c->multi_K = forced_k; c->ghost = forced_k;
+  } else if (forced_k < 0 && !self_periodic && obstacles_global && macro_eligible(p, ny_local, flags)) {
+    const int k = macro_k_for(c->ncells);
+    if (k > 0) { c->multi_K = k; c->ghost = k; }
   }
   c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
   c->ps = plane_stride_floats(c->ncells_storage);
@@ -409,17 +488,16 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   // obstacle bitfield
   const size_t mwords = (c->ncells_storage + 31) / 32 + 4;
   std::vector<uint32_t> bits(mwords, 0u);
-  if (c->ghost == 0) {
-    for (size_t i = 0; i < c->ncells; ++i)
-      if (obstacles_rows[i]) bits[i >> 5] |= 1u << (i & 31);
-  } else {
-    for (int r = 0; r < ny_local + 2 * c->ghost; ++r) {          // storage row -> global row, periodic
-      int g = (y0 + r - c->ghost) % p->ny;
-      if (g < 0) g += p->ny;
-      const int* row = obstacles_global + static_cast<size_t>(g) * p->nx;
-      for (int x = 0; x < p->nx; ++x)
-        if (row[x]) { const size_t i = static_cast<size_t>(r) * p->nx + x; bits[i >> 5] |= 1u << (i & 31); }
-    }
+  {
+    const int nx = p->nx, ny = p->ny, ghost = c->ghost;
+    const int rows = ny_local + 2 * ghost;
+    if (ghost == 0) pack_obstacle_bits(bits, rows, nx, [&](int r) { return obstacles_rows + static_cast<size_t>(r) * nx; });
+    else if (obstacles_window) pack_obstacle_bits(bits, rows, nx, [&](int r) { return obstacles_window + static_cast<size_t>(r) * nx; });
+    else pack_obstacle_bits(bits, rows, nx, [&](int r) {          // storage row -> global row, periodic
+      int g = (y0 + r - ghost) % ny;
+      if (g < 0) g += ny;
+      return obstacles_global + static_cast<size_t>(g) * nx;
+    });
   }
   c->mask_words = static_cast<int>(mwords);
   HIP_TRY_C(hipMalloc(&c->mask, sizeof(uint32_t) * mwords));
@@ -487,6 +565,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     }
   }
   for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->partials[i], sizeof(double) * c->partials_cap));
+  HIP_TRY_C(hipMalloc(&c->fold_scratch, sizeof(double) * kFoldSlices * 8));
   HIP_TRY_C(hipMalloc(&c->counter, sizeof(int)));
   HIP_TRY_C(hipMemsetAsync(c->counter, 0, sizeof(int), c->stream));
   // initial state (d2q9-bgk.c:880-902)
@@ -507,14 +586,43 @@ extern "C" {
 int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows, int y0,
                int ny_local, int device, unsigned flags)
 {
-  return create_impl(out, p, free_cells, obstacles_rows, nullptr, y0, ny_local, device, flags);
+  return create_impl(out, p, free_cells, obstacles_rows, nullptr, nullptr, 0, y0, ny_local, device, flags);
 }
 
 int lbm_create_global(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_all, int y0,
                       int ny_local, int device, unsigned flags)
 {
   if (!obstacles_all || !p || y0 < 0) { lbm_internal::set_error("lbm_create_global: bad argument"); return 1; }
-  return create_impl(out, p, free_cells, obstacles_all + static_cast<size_t>(y0) * p->nx, obstacles_all, y0, ny_local, device, flags);
+  return create_impl(out, p, free_cells, obstacles_all + static_cast<size_t>(y0) * p->nx, obstacles_all, nullptr, -1, y0, ny_local, device, flags);
+}
+
+// One mode and one K for every rank of a run, from global quantities only (see the header).
+int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, lbm_layout* out)
+{
+  if (!p || !out || nranks < 1 || rank < 0 || rank >= nranks) { lbm_internal::set_error("lbm_rank_layout: bad argument"); return 1; }
+  if (p->nx < 1 || p->ny < 3 || p->ny < nranks) { lbm_internal::set_error("lbm_rank_layout: grid too small for this many ranks"); return 1; }
+  std::vector<int> nyl(nranks), dis(nranks);
+  if (lbm_decompose(p->ny, nranks, nyl.data(), dis.data())) return 1;                 // d2q9-bgk.c:834-862
+  const int lo = *std::min_element(nyl.begin(), nyl.end()), hi = *std::max_element(nyl.begin(), nyl.end());
+  if (lo < 1) { lbm_internal::set_error("lbm_rank_layout: a rank would own no rows"); return 1; }
+  out->y0 = dis[rank];
+  out->ny_local = nyl[rank];
+  out->macro_k = 0;
+  const bool partitioned = nranks > 1 || (flags & LBM_FLAG_FORCE_HALO);
+  if (partitioned && macro_eligible(p, lo, flags) && macro_eligible(p, hi, flags))
+    out->macro_k = macro_k_for(static_cast<size_t>(p->nx) * hi);
+  out->ghost = out->macro_k;
+  return 0;
+}
+
+int lbm_create_rank(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacle_window, int nranks,
+                    int rank, int device, unsigned flags)
+{
+  lbm_layout lay;
+  if (!obstacle_window) { lbm_internal::set_error("lbm_create_rank: null argument"); return 1; }
+  if (lbm_rank_layout(p, nranks, rank, flags, &lay)) return 1;
+  const int* rows = obstacle_window + static_cast<size_t>(lay.ghost) * p->nx;          // the owned rows inside the window
+  return create_impl(out, p, free_cells, rows, nullptr, obstacle_window, lay.macro_k, lay.y0, lay.ny_local, device, flags);
 }
 
 int lbm_destroy(lbm_ctx* c)
@@ -529,6 +637,7 @@ int lbm_destroy(lbm_ctx* c)
   for (float* b : c->macro_pack) if (b) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) if (c->partials[i]) (void)hipFree(c->partials[i]);
   if (c->sums) (void)hipFree(c->sums);
+  if (c->fold_scratch) (void)hipFree(c->fold_scratch);
   if (c->counter) (void)hipFree(c->counter);
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -600,10 +709,7 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   HIP_TRY(hipEventRecord(c->ev_end, s));
   c->ev_launches = (multi || c->tile_kernel) ? c->ev_tile_launches : n_steps;
   c->ev_valid = true;
-  hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
-  HIP_TRY(hipGetLastError());
-  c->n_prev = 0;
-  c->n_prev_vecs = 1;
+  if (fold_last(c, s)) return 1;
   c->run_done = n_steps;
   if (av_vels) {
     std::vector<double> host(static_cast<size_t>(n_steps));
@@ -655,6 +761,53 @@ int lbm_set_cells(lbm_ctx* c, const float* cells_aos)
   return 0;
 }
 
+int lbm_get_observables(lbm_ctx* c, float* obs)
+{
+  if (!c || !obs) { lbm_internal::set_error("lbm_get_observables: null argument"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  // row blocks of at most 16 M cells through a 256 MB device buffer: no second copy of the state
+  const size_t chunk = std::min<size_t>(c->ncells, size_t(16) << 20);
+  float* tmp = nullptr;
+  HIP_TRY(hipMalloc(&tmp, sizeof(float) * 4 * chunk));
+  hipError_t e = hipSuccess;
+  const float* owned = c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx;
+  for (size_t c0 = 0; c0 < c->ncells && e == hipSuccess; c0 += chunk) {
+    const size_t n = std::min(chunk, c->ncells - c0);
+    hipLaunchKernelGGL(lbm_observables_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                       owned + c0, c->ps, n, tmp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(obs + 4 * c0, tmp, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  (void)hipFree(tmp);
+  HIP_TRY(e);
+  return 0;
+}
+
+int lbm_state_checksum(lbm_ctx* c, int y_begin, int y_end, unsigned long long* digest)
+{
+  if (!c || !digest) { lbm_internal::set_error("lbm_state_checksum: null argument"); return 1; }
+  if (y_begin < c->y0 || y_end > c->y0 + c->nyl || y_begin > y_end) { lbm_internal::set_error("lbm_state_checksum: rows outside the partition"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long* dev = nullptr;
+  HIP_TRY(hipMalloc(&dev, sizeof *dev));
+  const size_t nx = static_cast<size_t>(c->p.nx);
+  const size_t n = static_cast<size_t>(y_end - y_begin) * nx;
+  const size_t c0 = (static_cast<size_t>(c->ghost) + static_cast<size_t>(y_begin - c->y0)) * nx;
+  hipError_t e = hipMemsetAsync(dev, 0, sizeof *dev, c->stream);
+  if (e == hipSuccess && n > 0) {
+    const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 4096));
+    hipLaunchKernelGGL(lbm_checksum_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, c->grid[c->cur] + c0, c->ps, n,
+                       static_cast<unsigned long long>(y_begin) * nx, dev);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(digest, dev, sizeof *dev, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dev);
+  HIP_TRY(e);
+  return 0;
+}
+
 int lbm_av_velocity_sum(lbm_ctx* c, double* tot_u)
 {
   if (!c || !tot_u) { lbm_internal::set_error("lbm_av_velocity_sum: null argument"); return 1; }
@@ -662,10 +815,11 @@ int lbm_av_velocity_sum(lbm_ctx* c, double* tot_u)
   const int blocks = static_cast<int>(std::min<size_t>((c->ncells + kBlock - 1) / kBlock, 1024));
   double* part = nullptr;
   HIP_TRY(hipMalloc(&part, sizeof(double) * blocks));
-  // owned rows only; in K-step mode they start ghost rows in (ghost*nx is a multiple of 64 cells there)
+  // owned rows only; in K-step mode they start ghost rows in: bit offset ghost*nx of the bitfield (any value:
+  // nx = 130, K = 3 gives 390)
   hipLaunchKernelGGL(lbm_av_velocity_kernel, dim3(blocks), dim3(kBlock), 0, c->stream,
                      c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps,
-                     c->mask + static_cast<size_t>(c->ghost) * c->p.nx / 32, c->ncells, part);
+                     c->mask, static_cast<size_t>(c->ghost) * c->p.nx, c->ncells, part);
   std::vector<double> host(blocks);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, sizeof(double) * blocks, hipMemcpyDeviceToHost, c->stream);
@@ -763,9 +917,7 @@ int lbm_step_finish(lbm_ctx* c, void* stream)
     HIP_TRY(hipEventRecord(c->ev_end, s));
     c->ev_launches = c->run_steps * ((c->n_part_interior > 0 ? 1 : 0) + 1);
     c->ev_valid = true;
-    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
-    HIP_TRY(hipGetLastError());
-    c->n_prev = 0;
+    if (fold_last(c, s)) return 1;
   }
   return 0;
 }
@@ -893,10 +1045,7 @@ int lbm_macro_finish(lbm_ctx* c, void* stream)
     HIP_TRY(hipEventRecord(c->ev_end, s));
     c->ev_launches = c->ev_tile_launches;
     c->ev_valid = true;
-    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->partials[c->parity ^ 1], c->n_prev, c->n_prev_vecs, c->sums, c->counter);
-    HIP_TRY(hipGetLastError());
-    c->n_prev = 0;
-    c->n_prev_vecs = 1;
+    if (fold_last(c, s)) return 1;
   }
   return 0;
 }
@@ -913,6 +1062,12 @@ int lbm_macro_exchange_local(lbm_ctx* dst, lbm_ctx* src, int dir, void* stream)
   for (int k = 0; k < 9; ++k)
     HIP_TRY(hipMemcpyAsync(lbm_macro_recv_ptr(dst, dir ^ 1, k), lbm_macro_send_ptr(src, dir, k), bytes, hipMemcpyDeviceToDevice, s));
   return 0;
+}
+
+int lbm_step_fold(lbm_ctx* c, void* stream)
+{
+  if (!c) { lbm_internal::set_error("lbm_step_fold: null context"); return 1; }
+  return fold_last(c, pick_stream(c, stream));
 }
 
 int lbm_step_collect(lbm_ctx* c, void* stream, double* tot_u_per_step, int n_steps)
@@ -957,3 +1112,5 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 }
 
 }  // extern "C"
+
+#include "lbm_p2p_impl.h"   // peer-to-peer halo transport: drives the K-step launches above (include/lbm_d2q9_p2p.h)

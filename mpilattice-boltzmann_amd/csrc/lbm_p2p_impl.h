@@ -1,0 +1,416 @@
+// lbm_p2p_impl.h — host half of the peer-to-peer halo transport (include/lbm_d2q9_p2p.h).
+// Included at the end of lbm_kernels.hip: it drives the K-step launches of a context directly
+// (launch_multi, begin_run, fold_last) and owns the streams / events / mapped peer memory of one rank.
+//
+// Per macro-step (K steps) of one rank, reference lines d2q9-bgk.c:
+//
+//   compute stream                    edge stream
+//   ──────────────                    ───────────
+//   wait(edge rows m-1)               wait kernel: both neighbours' flags >= epoch(m)   MPI_Waitall (:364)
+//   interior tiles m      (:350)      wait(interior m-1)
+//   record(interior m)                edge tile rows m                        (:365-366)
+//                                     push kernel: my edge rows of the NEW state -> neighbours' ghost rows,
+//                                                  flags := epoch(m+1)                  MPI_Startall (:327)
+//                                     record(edge rows m)
+//
+// Small partitions (< 2 M cells) run everything on the compute stream with ONE launch over all tiles:
+// there the two cross-queue waits cost more than the overlap hides (measured for the RCCL loop).
+#pragma once
+
+#include <unistd.h>
+
+#include "lbm_d2q9_p2p.h"
+
+namespace {
+
+constexpr uint32_t kP2PMagic = 0x4C424D50u;   // "LBMP"
+
+struct P2PBlob {                       // what every rank tells every other rank (POD, <= LBM_P2P_HANDLE_BYTES)
+  uint32_t magic, version;
+  int32_t pid, device, nranks, rank;
+  int32_t nx, ny, y0, nyl, ghost, K, cur, ipc_ok;
+  uint64_t ps, window_bytes, reduce_cap;
+  uint64_t grid_ptr[2], window_ptr;    // raw device pointers: valid inside the exporting process
+  hipIpcMemHandle_t grid_h[2], window_h;
+  char host[64];
+};
+static_assert(sizeof(P2PBlob) <= LBM_P2P_HANDLE_BYTES, "blob fits the handle");
+
+struct P2PPeer {
+  bool mapped = false, ipc = false;
+  float* grid_alloc[2] = {nullptr, nullptr};   // base of the peer's two grid allocations in MY address space
+  char* window = nullptr;
+  P2PBlob blob{};
+};
+
+}  // namespace
+
+struct lbm_p2p {
+  lbm_ctx* ctx = nullptr;
+  int nranks = 1, rank = 0, south = 0, north = 0;
+  hipStream_t compute = nullptr, edge = nullptr;
+  hipEvent_t edge_done = nullptr, interior_done = nullptr;
+  bool edge_stream = true;             // edge rows on their own stream beside the interior launch
+  char* window = nullptr;              // my exported window: header + reduce slots [2][nranks][cap]
+  size_t window_bytes = 0, reduce_cap = 0;
+  const char* window_kind = "coarse";
+  int* err = nullptr;                  // host-mapped error word written by the wait kernels
+  unsigned int* done = nullptr;        // block-done counter of the push kernel
+  double* reduce_out = nullptr;        // folded global sums of one reduce round (device)
+  double** d_slots = nullptr;          // device arrays of per-rank pointers, [2 parities][nranks]
+  unsigned long long** d_flags = nullptr;
+  std::vector<P2PPeer> peers;
+  bool connected = false;
+  unsigned long long epoch = 0, reduce_round = 0;
+  long long timeout_ticks = 0;
+};
+
+namespace {
+
+P2PWindowHeader* header_of(char* w) { return reinterpret_cast<P2PWindowHeader*>(w); }
+double* slot_of(char* w, size_t cap, int nranks, int parity, int r)
+{
+  return reinterpret_cast<double*>(w + kP2PHeaderBytes) + (static_cast<size_t>(parity) * nranks + r) * cap;
+}
+
+void p2p_unmap(lbm_p2p* t)
+{
+  for (P2PPeer& p : t->peers) {
+    if (p.mapped && p.ipc) {
+      for (float*& g : p.grid_alloc) { if (g) (void)hipIpcCloseMemHandle(g); g = nullptr; }
+      if (p.window) (void)hipIpcCloseMemHandle(p.window);
+    }
+    p = P2PPeer{};
+  }
+}
+
+// The K rows of the CURRENT grid that the neighbours need, into their ghost rows of the grid with the same
+// parity, flags := epoch.
+int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
+{
+  lbm_ctx* c = t->ctx;
+  const P2PPeer& ps = t->peers[t->south];
+  const P2PPeer& pn = t->peers[t->north];
+  const int K = c->ghost, nx = c->p.nx, g = c->cur;
+  P2PPushArgs a{};
+  a.src = c->grid[g];
+  a.ps = c->ps;
+  // south neighbour: its top ghost rows start at storage row ghost + nyl(south); north neighbour: row 0
+  a.dst[0] = ps.grid_alloc[g] + 64 + static_cast<size_t>(ps.blob.ghost + ps.blob.nyl) * nx;
+  a.dst[1] = pn.grid_alloc[g] + 64;
+  a.dst_ps[0] = ps.blob.ps;
+  a.dst_ps[1] = pn.blob.ps;
+  a.src_row[0] = static_cast<size_t>(c->ghost);          // my first K owned rows
+  a.src_row[1] = static_cast<size_t>(c->nyl);            // my last K owned rows (ghost + nyl - K, ghost == K)
+  a.nfloats = K * nx;
+  a.flag[0] = &header_of(ps.window)->halo_flag[1];       // my rows arrive from the south neighbour's NORTH
+  a.flag[1] = &header_of(pn.window)->halo_flag[0];
+  a.parity_word[0] = &header_of(ps.window)->halo_parity[1];
+  a.parity_word[1] = &header_of(pn.window)->halo_parity[0];
+  a.epoch = epoch;
+  a.parity = static_cast<unsigned long long>(g);
+  a.done = t->done;
+  const dim3 grid((a.nfloats / 2 + 255) / 256, 9, 2);
+  hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int p2p_wait_halos(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
+{
+  P2PWindowHeader* h = header_of(t->window);
+  hipLaunchKernelGGL(lbm_p2p_wait_kernel, dim3(1), dim3(64), 0, s, h->halo_flag, h->halo_parity, 2, epoch,
+                     static_cast<unsigned long long>(t->ctx->cur), t->timeout_ticks, t->err);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
+{
+  if (!out || !ctx || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) { lbm_internal::set_error("lbm_p2p_create: bad argument (1..64 ranks)"); return 1; }
+  *out = nullptr;
+  if (ctx->ghost == 0 || ctx->multi_K == 0) {
+    lbm_internal::set_error("lbm_p2p_create: the context is not in K-step mode (lbm_create_rank / lbm_create_global; lbm_macro_steps() > 0)");
+    return 1;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  lbm_p2p* t = new lbm_p2p();
+  t->ctx = ctx;
+  t->nranks = nranks;
+  t->rank = rank;
+  t->south = (rank + nranks - 1) % nranks;   // `top`    d2q9-bgk.c:245-246
+  t->north = (rank + 1) % nranks;            // `bottom` d2q9-bgk.c:247
+  t->compute = ctx->stream;
+  t->peers.resize(nranks);
+  t->timeout_ticks = static_cast<long long>(tune_env("LBM_P2P_TIMEOUT_MS", 30000)) * 100000LL;   // wall_clock64: 100 MHz
+  // default by size, as the RCCL loop: an own stream for the edge rows pays once the interior launch is long
+  // enough to cover two cross-queue waits
+  t->edge_stream = ctx->ncells >= (size_t(1) << 21);
+  if (const char* sched = std::getenv("LBM_P2P_SCHEDULE")) {
+    if (std::string(sched) == "serial") t->edge_stream = false;
+    if (std::string(sched) == "edge") t->edge_stream = true;
+  }
+  auto fail = [&]() { lbm_p2p_destroy(t); return 1; };
+#define P2P_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      lbm_internal::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return fail();                                                                         \
+    }                                                                                        \
+  } while (0)
+  P2P_TRY(hipStreamCreateWithFlags(&t->edge, hipStreamNonBlocking));
+  P2P_TRY(hipEventCreateWithFlags(&t->edge_done, hipEventDisableTiming));
+  P2P_TRY(hipEventCreateWithFlags(&t->interior_done, hipEventDisableTiming));
+  // exported window: flags + reduce slots.  Uncached device memory, so that a flag raised by a peer is seen
+  // by a kernel that is already running here; fine-grained, then ordinary memory as fall-backs.
+  t->reduce_cap = static_cast<size_t>(std::max(ctx->p.max_iters, 4096));
+  t->window_bytes = kP2PHeaderBytes + sizeof(double) * 2 * nranks * t->reduce_cap;
+  void* w = nullptr;
+  if (tune_env("LBM_P2P_WINDOW", 0) <= 0 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocUncached) == hipSuccess) t->window_kind = "uncached";
+  else if (tune_env("LBM_P2P_WINDOW", 0) <= 1 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocFinegrained) == hipSuccess) t->window_kind = "fine-grained";
+  else { (void)hipGetLastError(); P2P_TRY(hipMalloc(&w, t->window_bytes)); t->window_kind = "coarse"; }
+  (void)hipGetLastError();
+  t->window = static_cast<char*>(w);
+  P2P_TRY(hipMemset(t->window, 0, t->window_bytes));
+  P2P_TRY(hipHostMalloc(reinterpret_cast<void**>(&t->err), sizeof(int), hipHostMallocMapped));
+  *t->err = 0;
+  P2P_TRY(hipMalloc(&t->done, sizeof(unsigned int)));
+  P2P_TRY(hipMemset(t->done, 0, sizeof(unsigned int)));
+  P2P_TRY(hipMalloc(&t->reduce_out, sizeof(double) * t->reduce_cap));
+  P2P_TRY(hipMalloc(&t->d_slots, sizeof(double*) * 2 * nranks));
+  P2P_TRY(hipMalloc(&t->d_flags, sizeof(unsigned long long*) * nranks));
+  P2P_TRY(hipDeviceSynchronize());
+#undef P2P_TRY
+  *out = t;
+  return 0;
+}
+
+int lbm_p2p_handle(lbm_p2p* t, void* blob_out)
+{
+  if (!t || !blob_out) { lbm_internal::set_error("lbm_p2p_handle: null argument"); return 1; }
+  lbm_ctx* c = t->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  P2PBlob b{};
+  b.magic = kP2PMagic; b.version = LBM_ABI_VERSION;
+  b.pid = static_cast<int32_t>(getpid()); b.device = c->device; b.nranks = t->nranks; b.rank = t->rank;
+  b.nx = c->p.nx; b.ny = c->p.ny; b.y0 = c->y0; b.nyl = c->nyl; b.ghost = c->ghost; b.K = c->multi_K; b.cur = c->cur;
+  b.ps = c->ps; b.window_bytes = t->window_bytes; b.reduce_cap = t->reduce_cap;
+  // IPC handles serve peers in OTHER processes; contexts of one process use the raw pointers, so a
+  // runtime that cannot export a handle only rules out the multi-process form (checked at connect)
+  b.ipc_ok = 1;
+  for (int g = 0; g < 2; ++g) {
+    b.grid_ptr[g] = reinterpret_cast<uint64_t>(c->grid_alloc[g]);
+    if (hipIpcGetMemHandle(&b.grid_h[g], c->grid_alloc[g]) != hipSuccess) b.ipc_ok = 0;
+  }
+  b.window_ptr = reinterpret_cast<uint64_t>(t->window);
+  if (hipIpcGetMemHandle(&b.window_h, t->window) != hipSuccess) b.ipc_ok = 0;
+  (void)hipGetLastError();
+  (void)gethostname(b.host, sizeof b.host - 1);
+  std::memset(blob_out, 0, LBM_P2P_HANDLE_BYTES);
+  std::memcpy(blob_out, &b, sizeof b);
+  return 0;
+}
+
+int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
+{
+  if (!t || !blobs) { lbm_internal::set_error("lbm_p2p_connect: null argument"); return 1; }
+  lbm_ctx* c = t->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  p2p_unmap(t);
+  t->connected = false;
+  const char* base = static_cast<const char*>(blobs);
+  const int32_t me = static_cast<int32_t>(getpid());
+  char host[64] = {0};
+  (void)gethostname(host, sizeof host - 1);
+  int rows = 0;
+  for (int r = 0; r < t->nranks; ++r) {
+    P2PPeer& p = t->peers[r];
+    std::memcpy(&p.blob, base + static_cast<size_t>(r) * LBM_P2P_HANDLE_BYTES, sizeof(P2PBlob));
+    const P2PBlob& b = p.blob;
+    // every rank must run the same K-step layout: a mismatch would mean different message sizes and
+    // exchange cadence, i.e. a hang or corrupted ghost rows (an error here instead)
+    if (b.magic != kP2PMagic || b.version != LBM_ABI_VERSION || b.rank != r || b.nranks != t->nranks) {
+      lbm_internal::set_error("lbm_p2p_connect: handle " + std::to_string(r) + " is not rank " + std::to_string(r) + " of this run");
+      return 1;
+    }
+    if (b.nx != c->p.nx || b.ny != c->p.ny || b.K != c->multi_K || b.ghost != c->ghost || b.cur != c->cur || b.reduce_cap != t->reduce_cap) {
+      lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " runs a different layout (nx " + std::to_string(b.nx) + ", ny " +
+                              std::to_string(b.ny) + ", K " + std::to_string(b.K) + ") than rank " + std::to_string(t->rank) + " (K " +
+                              std::to_string(c->multi_K) + "): create every rank with lbm_create_rank");
+      return 1;
+    }
+    if (std::strncmp(b.host, host, sizeof host) != 0) {
+      lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " runs on another host; peer-to-peer halos need one node");
+      return 1;
+    }
+    rows += b.nyl;
+  }
+  if (rows != c->p.ny) { lbm_internal::set_error("lbm_p2p_connect: the ranks' rows do not add up to ny"); return 1; }
+  for (int r = 0; r < t->nranks; ++r) {
+    P2PPeer& p = t->peers[r];
+    const P2PBlob& b = p.blob;
+    const bool neighbour = r == t->south || r == t->north;
+    if (r == t->rank) {                                        // myself: a 1-rank ring, or my own reduce slot
+      for (int g = 0; g < 2; ++g) p.grid_alloc[g] = c->grid_alloc[g];
+      p.window = t->window;
+    } else if (b.pid == me) {                                  // another context of this process: plain pointers
+      if (b.device != c->device) {
+        hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+          lbm_internal::set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+          return 1;
+        }
+        (void)hipGetLastError();
+      }
+      for (int g = 0; g < 2; ++g) p.grid_alloc[g] = reinterpret_cast<float*>(b.grid_ptr[g]);
+      p.window = reinterpret_cast<char*>(b.window_ptr);
+    } else {                                                   // another process: map its memory
+      if (!b.ipc_ok) {
+        lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " could not export IPC handles for its memory (hipIpcGetMemHandle failed; is HSA_ENABLE_IPC_MODE_LEGACY=0 set ?)");
+        return 1;
+      }
+      p.ipc = true;
+      void* q = nullptr;
+      HIP_TRY(hipIpcOpenMemHandle(&q, b.window_h, hipIpcMemLazyEnablePeerAccess));
+      p.window = static_cast<char*>(q);
+      p.mapped = true;
+      if (neighbour) {
+        for (int g = 0; g < 2; ++g) {
+          HIP_TRY(hipIpcOpenMemHandle(&q, b.grid_h[g], hipIpcMemLazyEnablePeerAccess));
+          p.grid_alloc[g] = static_cast<float*>(q);
+        }
+      }
+    }
+    p.mapped = true;
+  }
+  // device tables for the reduce kernels: where my sums go in every rank's window, and my flag there
+  std::vector<double*> slots(static_cast<size_t>(2) * t->nranks);
+  std::vector<unsigned long long*> flags(t->nranks);
+  for (int r = 0; r < t->nranks; ++r) {
+    for (int par = 0; par < 2; ++par) slots[static_cast<size_t>(par) * t->nranks + r] = slot_of(t->peers[r].window, t->reduce_cap, t->nranks, par, t->rank);
+    flags[r] = &header_of(t->peers[r].window)->reduce_flag[t->rank];
+  }
+  HIP_TRY(hipMemcpy(t->d_slots, slots.data(), sizeof(double*) * slots.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(t->d_flags, flags.data(), sizeof(unsigned long long*) * flags.size(), hipMemcpyHostToDevice));
+  t->connected = true;
+  return 0;
+}
+
+int lbm_p2p_destroy(lbm_p2p* t)
+{
+  if (!t) return 0;
+  if (t->ctx) (void)hipSetDevice(t->ctx->device);
+  if (t->edge) (void)hipStreamSynchronize(t->edge);
+  if (t->compute) (void)hipStreamSynchronize(t->compute);
+  p2p_unmap(t);
+  if (t->window) (void)hipFree(t->window);
+  if (t->err) (void)hipHostFree(t->err);
+  if (t->done) (void)hipFree(t->done);
+  if (t->reduce_out) (void)hipFree(t->reduce_out);
+  if (t->d_slots) (void)hipFree(t->d_slots);
+  if (t->d_flags) (void)hipFree(t->d_flags);
+  if (t->edge_done) (void)hipEventDestroy(t->edge_done);
+  if (t->interior_done) (void)hipEventDestroy(t->interior_done);
+  if (t->edge) (void)hipStreamDestroy(t->edge);
+  delete t;
+  return 0;
+}
+
+int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
+{
+  if (!t || n_steps < 0 || (n_steps > 0 && !tot_u_per_step)) { lbm_internal::set_error("lbm_p2p_run: bad argument"); return 1; }
+  if (!t->connected) { lbm_internal::set_error("lbm_p2p_run: call lbm_p2p_connect first"); return 1; }
+  if (n_steps == 0) return 0;
+  lbm_ctx* c = t->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const int K = c->multi_K;
+  hipStream_t cs = t->compute, es = t->edge_stream ? t->edge : t->compute;
+  if (begin_run(c, n_steps, cs)) return 1;                     // step-0 accelerate_flow (d2q9-bgk.c:345-348)
+  HIP_TRY(hipEventRecord(t->interior_done, cs));
+  if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
+  // the rows my neighbours need for the first macro-step (the state may have been set since the last run)
+  unsigned long long epoch = t->epoch + 1;
+  if (p2p_push(t, epoch, es)) return 1;
+  HIP_TRY(hipEventRecord(t->edge_done, es));
+  const MacroRows rows = macro_rows(c);
+  for (int done = 0; done < n_steps; ++epoch) {
+    const int k = std::min(K, n_steps - done);
+    const bool more = done + k < n_steps;
+    if (t->edge_stream) {
+      if (rows.interior_rows > 0) {                            // :350, beside the exchange
+        HIP_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+        launch_multi(c, k, more, c->multi_tiles_x, c->multi_tiles_x * rows.interior_rows, 0, 0, /*fold=*/c->n_prev > 0, cs);
+        c->n_prev = 0;
+      }
+      if (p2p_wait_halos(t, epoch, es)) return 1;              // MPI_Waitall (:364), on the device
+      HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
+      launch_multi(c, k, more, 0, c->multi_tiles_x, (1 + rows.interior_rows) * c->multi_tiles_x, rows.top_edge_rows * c->multi_tiles_x,
+                   /*fold=*/c->n_prev > 0, es);               // :365-366
+      c->n_prev = 0;
+      HIP_TRY(hipEventRecord(t->interior_done, cs));
+    } else {
+      if (p2p_wait_halos(t, epoch, cs)) return 1;
+      launch_multi(c, k, more, 0, c->multi_tiles, 0, 0, /*fold=*/c->n_prev > 0, cs);
+      c->n_prev = 0;
+    }
+    HIP_TRY(hipGetLastError());
+    // state flip of lbm_macro_finish (d2q9-bgk.c:376-378)
+    c->n_prev = c->multi_tiles;
+    c->n_prev_vecs = k;
+    c->parity ^= 1;
+    c->cur ^= 1;
+    c->run_done += k;
+    c->ev_tile_launches += t->edge_stream ? 2 : 1;
+    done += k;
+    if (more) {
+      if (p2p_push(t, epoch + 1, es)) return 1;                // MPI_Startall (:327) for the next macro-step
+    }
+    if (t->edge_stream) HIP_TRY(hipEventRecord(t->edge_done, es));
+  }
+  t->epoch = epoch - 1;
+  if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+  HIP_TRY(hipEventRecord(c->ev_end, cs));
+  c->ev_launches = c->ev_tile_launches;
+  c->ev_valid = true;
+  if (fold_last(c, cs)) return 1;
+  // MPI_Reduce (:396): all-gather of the per-step sums into every rank's window, local sum in rank order
+  for (int t0 = 0; t0 < n_steps; t0 += static_cast<int>(t->reduce_cap)) {
+    const int n = std::min(n_steps - t0, static_cast<int>(t->reduce_cap));
+    const unsigned long long round = ++t->reduce_round;
+    const int par = static_cast<int>(round & 1);
+    hipLaunchKernelGGL(lbm_p2p_gather_kernel, dim3((n + 255) / 256, t->nranks), dim3(256), 0, cs, c->sums + t0, n, t->d_slots + static_cast<size_t>(par) * t->nranks);
+    hipLaunchKernelGGL(lbm_p2p_reduce_signal_kernel, dim3(1), dim3(64), 0, cs, t->d_flags, t->nranks, round);
+    hipLaunchKernelGGL(lbm_p2p_wait_kernel, dim3(1), dim3(64), 0, cs, header_of(t->window)->reduce_flag, static_cast<const unsigned long long*>(nullptr),
+                       t->nranks, round, 0ull, t->timeout_ticks, t->err);
+    hipLaunchKernelGGL(lbm_p2p_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, cs, slot_of(t->window, t->reduce_cap, t->nranks, par, 0), t->reduce_cap,
+                       t->nranks, n, t->reduce_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+  }
+  HIP_TRY(hipStreamSynchronize(es));
+  if (*t->err != 0) {
+    const int e = *t->err;
+    const char* who = e >= 100 ? "a neighbour's grids are out of step with this rank's (different number of steps run ?)"
+                               : "a peer's data did not arrive in time (peer failed or never started the run ?)";
+    lbm_internal::set_error("lbm_p2p_run: rank " + std::to_string(t->rank) + ": " + who + " [code " + std::to_string(e) + "]");
+    return 1;
+  }
+  return 0;
+}
+
+int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)
+{
+  if (!t || !text || len == 0) { lbm_internal::set_error("lbm_p2p_describe: null argument"); return 1; }
+  const char* reach = "self";
+  if (t->nranks > 1) reach = (t->connected && t->peers[t->north].ipc) ? "ipc" : "in-process";
+  std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d", t->window_kind, reach, t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K);
+  return 0;
+}
+
+}  // extern "C"

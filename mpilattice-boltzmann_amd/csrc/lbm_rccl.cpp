@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -36,6 +37,7 @@ struct lbm_comm {
   hipStream_t side = nullptr;      // exchange stream
   hipStream_t edge = nullptr;      // boundary-row kernels
   hipEvent_t halo = nullptr, edge_done = nullptr, interior_done = nullptr;
+  bool step_allreduce = false;     // one all-reduce per (macro-)step instead of one after the loop
   bool three_queues = true;        // edge rows on their own stream beside the interior kernel; LBM_RCCL_SCHEDULE=serial
                                    // puts them on the compute stream after the interior kernel instead
 };
@@ -92,6 +94,28 @@ int lbm_comm_create(lbm_comm** out, lbm_ctx* ctx, const char id[LBM_COMM_ID_BYTE
   std::memcpy(&u, id, sizeof u);
   ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, u, rank);
   if (r != ncclSuccess) { lbm_internal::set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); c->nccl = nullptr; return fail(); }
+  if (nranks > 1) {
+    // every rank must run the same stepping mode with the same K and message size: ranks that disagree would
+    // post sends and receives of different sizes at different cadences (hang, or corrupted ghost rows).
+    // min and max over ranks of (K, message floats) must coincide.
+    long long mine[4], *dev = nullptr;
+    const long long k = lbm_macro_steps(ctx), n = k > 0 ? static_cast<long long>(lbm_macro_pack_floats(ctx)) : static_cast<long long>(lbm_halo_floats(ctx));
+    mine[0] = k; mine[1] = -k; mine[2] = n; mine[3] = -n;
+    hipStream_t s0 = c->compute;
+    bool ok = hipMalloc(&dev, sizeof mine) == hipSuccess && hipMemcpyAsync(dev, mine, sizeof mine, hipMemcpyHostToDevice, s0) == hipSuccess;
+    if (ok) {
+      r = ncclAllReduce(dev, dev, 4, ncclInt64, ncclMax, c->nccl, s0);
+      ok = r == ncclSuccess && hipMemcpyAsync(mine, dev, sizeof mine, hipMemcpyDeviceToHost, s0) == hipSuccess && hipStreamSynchronize(s0) == hipSuccess;
+    }
+    if (dev) (void)hipFree(dev);
+    if (!ok) { lbm_internal::set_error("lbm_comm_create: layout check (ncclAllReduce) failed"); return fail(); }
+    if (mine[0] != -mine[1] || mine[2] != -mine[3]) {
+      lbm_internal::set_error("lbm_comm_create: ranks disagree about the stepping mode (K between " + std::to_string(-mine[1]) + " and " +
+                              std::to_string(mine[0]) + ", halo message between " + std::to_string(-mine[3]) + " and " + std::to_string(mine[2]) +
+                              " floats): create every rank with lbm_create_rank");
+      return fail();
+    }
+  }
   const char* sched = std::getenv("LBM_RCCL_SCHEDULE");
   // default by size: three queues pay once the interior kernel is long enough to cover two extra
   // cross-queue waits (measured on MI355X: 8192x1024 rows 120 vs 133 us/step; 1024x128 rows 55 vs 34)
@@ -114,6 +138,20 @@ int lbm_comm_create(lbm_comm** out, lbm_ctx* ctx, const char id[LBM_COMM_ID_BYTE
     return fail();
   }
   *out = c;
+  return 0;
+}
+
+int lbm_comm_nranks(const lbm_comm* c)
+{
+  int n = 0;
+  if (!c || !c->nccl || ncclCommCount(c->nccl, &n) != ncclSuccess) return -1;
+  return n;
+}
+
+int lbm_comm_set_step_allreduce(lbm_comm* c, int on)
+{
+  if (!c) { lbm_internal::set_error("lbm_comm_set_step_allreduce: null communicator"); return 1; }
+  c->step_allreduce = on != 0;
   return 0;
 }
 
@@ -184,9 +222,17 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
       if (done + K >= n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
     }
     LBM_TRY(lbm_macro_finish(ctx, c->compute));
+    if (c->step_allreduce) {
+      // this macro-step's totals now, and the next macro-step behind their all-reduce (north_star wording)
+      const int k = std::min(K, n_steps - done);
+      if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+      LBM_TRY(lbm_step_fold(ctx, c->compute));
+      double* sums_now = static_cast<double*>(lbm_step_sums_device_ptr(ctx)) + done;
+      NCCL_TRY(ncclAllReduce(sums_now, sums_now, static_cast<size_t>(k), ncclDouble, ncclSum, c->nccl, c->compute));
+    }
   }
   double* sums = static_cast<double*>(lbm_step_sums_device_ptr(ctx));
-  if (c->nranks > 1) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));
+  if (c->nranks > 1 && !c->step_allreduce) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));
   LBM_TRY(lbm_step_collect(ctx, nullptr, tot_u_per_step, n_steps));
   HIP_TRY(hipStreamSynchronize(c->side));
   HIP_TRY(hipStreamSynchronize(c->edge));
@@ -236,10 +282,16 @@ int lbm_comm_run(lbm_comm* c, int n_steps, double* tot_u_per_step)
       if (t + 1 == n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));   // the final fold reads both
     }
     LBM_TRY(lbm_step_finish(ctx, c->compute));             // :376-378
+    if (c->step_allreduce) {
+      if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+      LBM_TRY(lbm_step_fold(ctx, c->compute));
+      double* sum_now = static_cast<double*>(lbm_step_sums_device_ptr(ctx)) + t;
+      NCCL_TRY(ncclAllReduce(sum_now, sum_now, 1, ncclDouble, ncclSum, c->nccl, c->compute));
+    }
   }
   // MPI_Reduce of the per-step vector (:396), as an in-place all-reduce on the compute stream
   double* sums = static_cast<double*>(lbm_step_sums_device_ptr(ctx));
-  if (c->nranks > 1) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));
+  if (c->nranks > 1 && !c->step_allreduce) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));
   LBM_TRY(lbm_step_collect(ctx, nullptr, tot_u_per_step, n_steps));
   HIP_TRY(hipStreamSynchronize(c->side));
   HIP_TRY(hipStreamSynchronize(c->edge));

@@ -67,6 +67,25 @@ def decompose(ny: int, size: int) -> tuple[list[int], list[int]]:
     return list(nyl), list(dis)
 
 
+def rank_layout(params: Params, nranks: int, rank: int, flags: int = 0) -> dict:
+    """`lbm_rank_layout`: rows of `rank` by the reference's rule (`d2q9-bgk.c:834-862`) plus the stepping
+    mode of the WHOLE run, derived from global quantities only — the same answer on every rank."""
+    lib = _capi.load_library()
+    lay = _capi.CLayout()
+    cp = _cparams(params)
+    check(lib.lbm_rank_layout(C.byref(cp), nranks, rank, flags, C.byref(lay)))
+    return {"y0": lay.y0, "ny_local": lay.ny_local, "macro_k": lay.macro_k, "ghost": lay.ghost}
+
+
+def obstacle_window(obstacles: np.ndarray, layout: dict) -> np.ndarray:
+    """The rows of the global map one rank needs: its owned rows plus `ghost` rows below and above,
+    wrapping periodically — what the root hands each rank instead of the reference's `MPI_Scatterv` of
+    the owned rows alone (`d2q9-bgk.c:968-970`)."""
+    ny = obstacles.shape[0]
+    rows = np.arange(layout["y0"] - layout["ghost"], layout["y0"] + layout["ny_local"] + layout["ghost"]) % ny
+    return np.ascontiguousarray(obstacles[rows], dtype=np.int32)
+
+
 def av_velocity_host(params: Params, cells: np.ndarray, obstacles: np.ndarray) -> float:
     """`av_velocity()` without the reduce (`d2q9-bgk.c:716-751`): float tot_u over the given rows."""
     lib = _capi.load_library()
@@ -75,6 +94,16 @@ def av_velocity_host(params: Params, cells: np.ndarray, obstacles: np.ndarray) -
     cp = _cparams(params)
     return float(lib.lbm_av_velocity_host(C.byref(cp), _capi.as_float_ptr(cells), _capi.as_int_ptr(obstacles),
                                           obstacles.shape[0]))
+
+
+def av_velocity_obs(params: Params, obs: np.ndarray, obstacles: np.ndarray) -> float:
+    """The same value from device-computed observables (`lbm_get_observables`): u_x, u_y are the floats of
+    `d2q9-bgk.c:732-746`; the double sqrt and the float accumulation (`:748`) happen here."""
+    lib = _capi.load_library()
+    obs = np.ascontiguousarray(obs, dtype=np.float32)
+    obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
+    cp = _cparams(params)
+    return float(lib.lbm_av_velocity_obs(C.byref(cp), _capi.as_float_ptr(obs), _capi.as_int_ptr(obstacles), obstacles.shape[0]))
 
 
 def reynolds(params: Params, av_velocity: float) -> float:
@@ -95,6 +124,17 @@ def write_final_state(path: str, params: Params, cells: np.ndarray, obstacles: n
                                     _capi.as_int_ptr(obstacles), obstacles.shape[0], displ, int(append)))
 
 
+def write_final_state_obs(path: str, params: Params, obs: np.ndarray, obstacles: np.ndarray, displ: int = 0,
+                          append: bool = False) -> None:
+    """The same file from `lbm_get_observables` output (4 floats per cell computed on the device)."""
+    lib = _capi.load_library()
+    obs = np.ascontiguousarray(obs, dtype=np.float32)
+    obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
+    cp = _cparams(params)
+    check(lib.lbm_write_final_state_obs(os.fsencode(path), C.byref(cp), _capi.as_float_ptr(obs),
+                                        _capi.as_int_ptr(obstacles), obstacles.shape[0], displ, int(append)))
+
+
 def write_av_vels(path: str, av_vels: np.ndarray) -> None:
     """`write_values()`'s av_vels.dat part (`d2q9-bgk.c:1127-1139`)."""
     lib = _capi.load_library()
@@ -110,9 +150,12 @@ class Partition:
     """Device state of rows [y0, y0+ny_local) — one `lbm_ctx` (include/lbm_d2q9.h)."""
 
     def __init__(self, params: Params, free_cells: int, obstacles_rows: np.ndarray, y0: int = 0,
-                 device: int = 0, flags: int = 0, obstacles_global: Optional[np.ndarray] = None):
+                 device: int = 0, flags: int = 0, obstacles_global: Optional[np.ndarray] = None,
+                 rank_of: Optional[tuple[int, int]] = None):
         """obstacles_global: the whole (ny, nx) map; when given (`lbm_create_global`) an eligible
-        row partition runs in K-step mode (`macro_steps` > 0) and obstacles_rows is ignored."""
+        row partition runs in K-step mode (`macro_steps` > 0) and obstacles_rows is ignored.
+        rank_of = (rank, nranks): obstacles_rows is this rank's obstacle WINDOW (`obstacle_window`) and the
+        context comes from `lbm_create_rank`, whose stepping mode is the same on every rank of the run."""
         self._lib = _capi.load_library()
         obst = np.ascontiguousarray(obstacles_rows, dtype=np.int32)
         if obst.ndim != 2 or obst.shape[1] != params.nx:
@@ -121,7 +164,15 @@ class Partition:
         self.free_cells_inv = np.float32(1.0) / np.float32(free_cells)          # d2q9-bgk.c:950
         self._ctx = C.c_void_p()
         cp = _cparams(params)
-        if obstacles_global is not None:
+        if rank_of is not None:
+            rank, nranks = rank_of
+            lay = rank_layout(params, nranks, rank, flags)
+            if obst.shape[0] != lay["ny_local"] + 2 * lay["ghost"]:
+                raise ValueError("obstacles_rows must be the rank's window: ny_local + 2*ghost rows")
+            self.y0, self.ny_local = lay["y0"], lay["ny_local"]
+            check(self._lib.lbm_create_rank(C.byref(self._ctx), C.byref(cp), free_cells, _capi.as_int_ptr(obst), nranks, rank,
+                                            device, flags))
+        elif obstacles_global is not None:
             glob = np.ascontiguousarray(obstacles_global, dtype=np.int32)
             if glob.shape != (params.ny, params.nx):
                 raise ValueError("obstacles_global must be (ny, nx)")
@@ -189,6 +240,21 @@ class Partition:
         if cells.shape != (self.ny_local, self.params.nx, _capi.NSPEEDS):
             raise ValueError("cells must be (ny_local, nx, 9)")
         check(self._lib.lbm_set_cells(self._ctx, _capi.as_float_ptr(cells)))
+
+    def get_observables(self) -> np.ndarray:
+        """(ny_local, nx, 4) float32: u_x, u_y, u, pressure per cell, computed on the device (`d2q9-bgk.c:1084-1111`)."""
+        obs = np.empty((self.ny_local, self.params.nx, 4), dtype=np.float32)
+        check(self._lib.lbm_get_observables(self._ctx, _capi.as_float_ptr(obs)))
+        return obs
+
+    def checksum(self, y_begin: Optional[int] = None, y_end: Optional[int] = None) -> int:
+        """`lbm_state_checksum` of the global rows [y_begin, y_end) (default: all owned rows): additive over
+        disjoint row ranges, so the ranks' digests sum (mod 2**64) to the whole grid's."""
+        y_begin = self.y0 if y_begin is None else y_begin
+        y_end = self.y0 + self.ny_local if y_end is None else y_end
+        d = C.c_ulonglong(0)
+        check(self._lib.lbm_state_checksum(self._ctx, y_begin, y_end, C.byref(d)))
+        return int(d.value)
 
     def av_velocity_sum(self) -> float:
         tot = C.c_double(0.0)
@@ -338,25 +404,48 @@ class RcclRing:
     overlapped with the interior kernel, one all-reduce at the end (`d2q9-bgk.c:295-313,326-327,364,396`).
     torch.distributed is used once, to hand rank 0's 128-byte RCCL id to every rank."""
 
-    def __init__(self, partition: "Partition", group=None, *, rank: Optional[int] = None, size: Optional[int] = None):
-        self._lib = _capi.load_rccl_library()
+    def __init__(self, partition: "Partition", group=None, *, rank: Optional[int] = None, size: Optional[int] = None,
+                 step_allreduce: bool = False):
         self.partition = partition
-        ident = C.create_string_buffer(_capi.COMM_ID_BYTES)
+        self._comm = C.c_void_p()
         if size is None:
+            import torch
             import torch.distributed as dist
             rank, size = dist.get_rank(group), dist.get_world_size(group)
-            box = [None]
-            if rank == 0:
-                check(self._lib.lbm_comm_unique_id(ident))
-                box[0] = ident.raw
+            # Two collectives follow (the id broadcast and ncclCommInitRank).  They may only be entered when
+            # EVERY rank can enter them, or the ranks that can would block in them for ever: agree first.
+            lib, ident, err = None, C.create_string_buffer(_capi.COMM_ID_BYTES), None
+            try:
+                lib = _capi.load_rccl_library()
+                if rank == 0:
+                    check(lib.lbm_comm_unique_id(ident))
+            except (LbmError, RuntimeError, OSError) as e:       # library missing on this node, RCCL error
+                err = e
+            on_host = dist.get_backend(group) == "gloo"
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                              device="cpu" if on_host else torch.device("cuda", partition.device))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) != 1:
+                raise LbmError(f"native RCCL loop unavailable on at least one rank ({err or 'this rank is fine'})")
+            self._lib = lib
+            box = [ident.raw if rank == 0 else None]
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
             ident = C.create_string_buffer(box[0], _capi.COMM_ID_BYTES)
         else:                                   # single process (size must be 1): exchange with itself
+            self._lib = _capi.load_rccl_library()
+            ident = C.create_string_buffer(_capi.COMM_ID_BYTES)
             check(self._lib.lbm_comm_unique_id(ident))
         self.rank, self.size = rank, size
-        self._comm = C.c_void_p()
         check(self._lib.lbm_comm_create(C.byref(self._comm), partition._ctx, ident, size, rank))
+        if step_allreduce:
+            check(self._lib.lbm_comm_set_step_allreduce(self._comm, 1))
+        self.step_allreduce = step_allreduce
+
+    @property
+    def nranks(self) -> int:
+        """Ranks of the communicator as RCCL reports it (`ncclCommCount`)."""
+        return int(self._lib.lbm_comm_nranks(self._comm))
 
     def run(self, n_steps: int) -> np.ndarray:
         """Global per-step tot_u (float64, n_steps), identical on every rank."""
@@ -368,6 +457,109 @@ class RcclRing:
         if getattr(self, "_comm", None) is not None and self._comm:
             self._lib.lbm_comm_destroy(self._comm)
             self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class P2PRing:
+    """The native step loop with direct peer-to-peer halo stores (include/lbm_d2q9_p2p.h) for one rank:
+    every K steps a kernel stores this rank's edge rows straight into the neighbours' ghost rows over
+    xGMI and raises an epoch flag there; no communication library on the path
+    (`d2q9-bgk.c:295-313,326-327,364,396`).  Set-up is `create` -> exchange of handles -> `connect`:
+      * across processes, `P2PRing(partition, group)` all-gathers the handles over torch.distributed;
+      * inside one process, `P2PRing.local_ring(partitions)` passes them in memory (ranks then run on one
+        host thread each, `run_all`)."""
+
+    def __init__(self, partition: "Partition", group=None, *, rank: Optional[int] = None, size: Optional[int] = None,
+                 connect: bool = True):
+        self._lib = _capi.load_library()
+        self.partition = partition
+        self._t = C.c_void_p()
+        if size is None:
+            import torch.distributed as dist
+            rank, size = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.size = rank, size
+        self._group = group
+        # every rank reaches the all-gather below whether or not its own set-up worked: a failure is
+        # carried in place of the handle and raised on all ranks together
+        blob, err = None, None
+        try:
+            check(self._lib.lbm_p2p_create(C.byref(self._t), partition._ctx, size, rank))
+            buf = C.create_string_buffer(_capi.P2P_HANDLE_BYTES)
+            check(self._lib.lbm_p2p_handle(self._t, buf))
+            blob = buf.raw
+        except LbmError as e:
+            err = str(e)
+        self.handle = blob
+        self._err = err
+        if connect:
+            import torch.distributed as dist
+            box = [None] * size
+            dist.all_gather_object(box, blob if err is None else ("error", err), group=group)
+            bad = [(r, b[1]) for r, b in enumerate(box) if isinstance(b, tuple)]
+            if bad:
+                self.close()
+                raise LbmError("peer-to-peer set-up failed on rank(s) " + "; ".join(f"{r}: {m}" for r, m in bad))
+            self.connect(box)
+            # nobody starts pushing rows into a neighbour that has not mapped its peers yet
+            dist.barrier(group=group)
+        elif err is not None:
+            raise LbmError(err)
+
+    def connect(self, handles: Sequence[bytes]) -> None:
+        check(self._lib.lbm_p2p_connect(self._t, b"".join(handles)))
+
+    @classmethod
+    def local_ring(cls, partitions: Sequence["Partition"]) -> list["P2PRing"]:
+        """Rings for several partitions of ONE process (same or different GPUs), connected in memory."""
+        n = len(partitions)
+        rings = [cls(p, rank=r, size=n, connect=False) for r, p in enumerate(partitions)]
+        handles = [r.handle for r in rings]
+        for r in rings:
+            r.connect(handles)
+        return rings
+
+    @staticmethod
+    def run_all(rings: Sequence["P2PRing"], n_steps: int) -> list[np.ndarray]:
+        """`run` of every ring of a process at once, one host thread per rank (each call blocks until its
+        rank's device work is done, and the ranks wait for one another's rows)."""
+        import threading
+        out: list = [None] * len(rings)
+
+        def work(i):
+            try:
+                out[i] = rings[i].run(n_steps)
+            except Exception as e:      # noqa: BLE001 - re-raised below on the calling thread
+                out[i] = e
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(rings))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for o in out:
+            if isinstance(o, Exception):
+                raise o
+        return out
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(self._lib.lbm_p2p_describe(self._t, buf, 256))
+        return buf.value.decode()
+
+    def run(self, n_steps: int) -> np.ndarray:
+        """Global per-step tot_u (float64, n_steps), bitwise identical on every rank."""
+        out = np.zeros(max(n_steps, 1), dtype=np.float64)
+        check(self._lib.lbm_p2p_run(self._t, n_steps, _capi.as_double_ptr(out)))
+        return out[:n_steps]
+
+    def close(self) -> None:
+        if getattr(self, "_t", None) is not None and self._t:
+            self._lib.lbm_p2p_destroy(self._t)
+            self._t = C.c_void_p()
 
     def __del__(self):
         try:
@@ -395,79 +587,138 @@ def run_partitioned(part: PartitionBackend, exchange: HaloExchange, n_steps: int
 # the CLI contract as an object
 # ------------------------------------------------------------------------------------------------
 
+EXCHANGES = ("auto", "p2p", "rccl", "torch")
+
+
 class Simulation:
     """paramfile + obstaclefile -> av_vels, final state, Reynolds number (the reference's `main`).
 
-    With a torch.distributed process group of size > 1 (one process per GPU), each rank owns the
-    rows `decompose()` gives it and `run()` performs the halo exchange over the group — by default in
-    the native RCCL loop, K steps per exchange where the partition is eligible (`lbm_create_global`,
-    `Partition.macro_steps`); otherwise the whole grid lives on one GPU and `run()` is one `lbm_run`."""
+    With a torch.distributed process group of size > 1 (one process per GPU), each rank owns the rows
+    `rank_layout()` gives it and `run()` performs the halo exchange — `loop` tells which way:
+      "p2p"    native loop, direct peer-to-peer stores into the neighbours' ghost rows (K-step mode only)
+      "rccl"   native loop of liblbm_d2q9_rccl.so, RCCL send/recv (K-step or one-step mode)
+      "torch"  one-step loop driven from Python over torch.distributed P2P ops
+      "single" the whole grid on one GPU, one `lbm_run`.
+    `exchange="auto"` picks p2p when the run is in K-step mode, else rccl.  With strict=False a native loop
+    that cannot be set up on every rank falls back to the next one (with a warning); with strict=True that
+    is an error — what ran is always `loop`, never the request."""
 
-    def __init__(self, params: Params, obstacles: np.ndarray, *, device: int = 0, flags: int = 0,
-                 distributed: bool = False, group=None, exchange: str = "rccl"):
-        """exchange: how a distributed run moves its halos — "rccl" = the native loop of
-        liblbm_d2q9_rccl.so (default), "torch" = torch.distributed P2P ops from Python."""
-        if exchange not in ("rccl", "torch"):
-            raise ValueError("exchange must be 'rccl' or 'torch'")
-        obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
-        if obstacles.shape != (params.ny, params.nx):
-            raise ValueError("obstacles must be (ny, nx)")
-        self.params, self.obstacles = params, obstacles
-        self.free_cells = count_free_cells(obstacles)
-        self.free_cells_inv = np.float32(1.0) / np.float32(self.free_cells)
+    def __init__(self, params: Params, obstacles: Optional[np.ndarray], *, device: int = 0, flags: int = 0,
+                 distributed: bool = False, group=None, exchange: str = "auto", strict: bool = False,
+                 free_cells: Optional[int] = None, step_allreduce: bool = False):
+        """obstacles: the whole (ny, nx) map — or, in a distributed run, None on every rank but 0: rank 0 then
+        hands each rank its window of rows (the reference's `MPI_Scatterv`, `d2q9-bgk.c:968-970`) and the
+        free-cell count (`MPI_Bcast`, `:966`)."""
+        if exchange not in EXCHANGES:
+            raise ValueError(f"exchange must be one of {EXCHANGES}")
+        self.params = params
         self.device = device
         self.exchange: Optional[HaloExchange] = None
         self.rank, self.size = 0, 1
+        self._group = group
         if distributed:
             self.exchange = HaloExchange(group)
             self.rank, self.size = self.exchange.rank, self.exchange.size
-        self.ny_local, self.displs = decompose(params.ny, self.size)
-        y0, nyl = self.displs[self.rank], self.ny_local[self.rank]
-        self.y0, self.nyl = y0, nyl
-        # the native RCCL loop runs eligible partitions in K-step mode (needs the whole obstacle map for
-        # the ghost rows); the torch loop drives the one-step split-phase calls
-        one_step = _capi.FLAG_ONE_STEP if exchange == "torch" else 0
-        self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device, flags | one_step,
-                                   obstacles_global=obstacles)
+        if obstacles is not None:
+            obstacles = np.ascontiguousarray(obstacles, dtype=np.int32)
+            if obstacles.shape != (params.ny, params.nx):
+                raise ValueError("obstacles must be (ny, nx)")
+        elif not distributed or self.rank == 0:
+            raise ValueError("obstacles may only be None on ranks other than 0 of a distributed run")
+        self.obstacles = obstacles          # whole map where this rank has it (rank 0 always), else None
+        self._partitioned = self.size > 1 or bool(flags & _capi.FLAG_FORCE_HALO)
+        self._flags = flags
         self._torch_device = None
         self._stream = None
         self._ring: Optional[RcclRing] = None
-        # a forced-halo whole-grid partition is a 1-rank ring that exchanges with itself (:245-247)
-        self._partitioned = self.size > 1 or bool(flags & _capi.FLAG_FORCE_HALO)
-        if self._partitioned and not distributed:
-            if exchange != "rccl":
-                raise ValueError("a forced-halo run outside torch.distributed needs exchange='rccl'")
-            self._ring = RcclRing(self.partition, rank=0, size=1)
-        elif self._partitioned and exchange == "rccl":
-            self._ring = self._ring_or_none(group)
-            if self._ring is None:      # every rank agreed: the native loop is unavailable, use the torch loop
-                self.partition.close()
-                self.partition = Partition(params, self.free_cells, obstacles[y0:y0 + nyl], y0, device,
-                                           flags | _capi.FLAG_ONE_STEP, obstacles_global=obstacles)
-                self._setup_torch_loop(device)
-        elif self._partitioned:
-            self._setup_torch_loop(device)
+        self._p2p: Optional[P2PRing] = None
+        self.step_allreduce = step_allreduce
+        if not self._partitioned:
+            self.free_cells = count_free_cells(obstacles) if free_cells is None else free_cells
+            self.free_cells_inv = np.float32(1.0) / np.float32(self.free_cells)
+            self.layout = {"y0": 0, "ny_local": params.ny, "macro_k": 0, "ghost": 0}
+            self.ny_local, self.displs = [params.ny], [0]
+            self.y0, self.nyl = 0, params.ny
+            self.partition = Partition(params, self.free_cells, obstacles, 0, device, flags)
+            self._window = obstacles
+            self.loop = "single"
+            return
+        self.ny_local, self.displs = decompose(params.ny, self.size)
+        want = exchange
+        if want == "auto":
+            want = "p2p"
+        if step_allreduce and want != "rccl":
+            if exchange in ("p2p", "torch"):
+                raise ValueError("step_allreduce is a mode of the RCCL loop")
+            want = "rccl"
+        # try the loops in order; what could not be set up on EVERY rank is skipped by all ranks together
+        order = {"p2p": ["p2p", "rccl", "torch"], "rccl": ["rccl", "torch"], "torch": ["torch"]}[want]
+        last_err = None
+        for loop in order:
+            one_step = _capi.FLAG_ONE_STEP if loop == "torch" else 0
+            self._make_partition(flags | one_step, free_cells)
+            if loop == "p2p" and self.partition.macro_steps == 0:
+                last_err = "the run is not in K-step mode (a rank has < 32 rows, or nx is odd / < 128)"
+                if exchange == "p2p" and strict:
+                    break
+                continue                      # a layout fact, the same on every rank: not a failure
+            try:
+                if loop == "p2p":
+                    self._p2p = P2PRing(self.partition, group) if distributed else P2PRing.local_ring([self.partition])[0]
+                elif loop == "rccl":
+                    self._ring = (RcclRing(self.partition, group, step_allreduce=step_allreduce) if distributed
+                                  else RcclRing(self.partition, rank=0, size=1, step_allreduce=step_allreduce))
+                else:
+                    if not distributed:
+                        raise LbmError("a forced-halo run outside torch.distributed needs a native loop (p2p or rccl)")
+                    self._setup_torch_loop(device)
+                self.loop = loop
+                return
+            except LbmError as e:             # raised on every rank together (see RcclRing / P2PRing)
+                last_err = str(e)
+                if strict:
+                    break
+                if self.rank == 0:
+                    import warnings
+                    warnings.warn(f"{loop} loop unavailable ({e}); falling back")
+        self.partition.close()
+        raise LbmError(f"no step loop could be set up for exchange={exchange!r}: {last_err}")
 
-    def _ring_or_none(self, group) -> Optional[RcclRing]:
-        """RcclRing, or None on EVERY rank if liblbm_d2q9_rccl.so or its communicator failed on any."""
-        import torch
-        import torch.distributed as dist
-        ring, err = None, None
-        try:
-            ring = RcclRing(self.partition, group)
-        except (LbmError, RuntimeError, OSError) as e:       # missing library, RCCL error
-            err = e
-        ok = torch.tensor([0 if ring is None else 1], dtype=torch.int32,
-                          device="cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", self.device))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
-            return ring
-        if ring is not None:
-            ring.close()
-        if self.rank == 0:
-            import warnings
-            warnings.warn(f"native RCCL loop unavailable ({err}); falling back to the torch.distributed loop")
-        return None
+    # -- set-up helpers --
+    def _make_partition(self, flags: int, free_cells: Optional[int]) -> None:
+        """(Re)create this rank's partition for `flags`: layout from global quantities, obstacle window from
+        the local map, or scattered by rank 0 when only rank 0 holds the map."""
+        if getattr(self, "partition", None) is not None:
+            if self._partition_flags == flags:
+                return
+            self.partition.close()
+        self._partition_flags = flags
+        lay = rank_layout(self.params, self.size, self.rank, flags)
+        self.layout = lay
+        self.y0, self.nyl = lay["y0"], lay["ny_local"]
+        if self.exchange is not None and self.size > 1:
+            import torch.distributed as dist
+            group = self._group
+            have = [None] * self.size
+            dist.all_gather_object(have, self.obstacles is not None, group=group)
+            if not all(have):
+                # scatter of obstacle rows (:968-970) + broadcast of the free-cell count (:966) from rank 0
+                box, wins = [None], None
+                if self.rank == 0:
+                    free = count_free_cells(self.obstacles) if free_cells is None else free_cells
+                    wins = [(obstacle_window(self.obstacles, rank_layout(self.params, self.size, r, flags)), free)
+                            for r in range(self.size)]
+                dist.scatter_object_list(box, wins, src=self.exchange._global(0), group=group)
+                self._finish_partition(box[0][0], box[0][1], flags)
+                return
+        free = count_free_cells(self.obstacles) if free_cells is None else free_cells
+        self._finish_partition(obstacle_window(self.obstacles, lay), free, flags)
+
+    def _finish_partition(self, window: np.ndarray, free_cells: int, flags: int) -> None:
+        self.free_cells = free_cells
+        self.free_cells_inv = np.float32(1.0) / np.float32(free_cells)
+        self._window = window
+        self.partition = Partition(self.params, free_cells, window, device=self.device, flags=flags, rank_of=(self.rank, self.size))
 
     def _setup_torch_loop(self, device: int) -> None:
         import torch
@@ -485,13 +736,23 @@ class Simulation:
         obstacles, _ = read_obstacles(obstaclefile, params.nx, params.ny)
         return cls(params, obstacles, **kw)
 
+    def describe(self) -> dict:
+        """What actually runs: loop, K, ranks as the transport itself reports them."""
+        d = {"loop": self.loop, "macro_k": self.partition.macro_steps, "ranks": self.size, "rccl_nranks": None, "p2p": None,
+             "step_allreduce": bool(self._ring is not None and self._ring.step_allreduce)}
+        if self._ring is not None:
+            d["rccl_nranks"] = self._ring.nranks
+        if self._p2p is not None:
+            d["p2p"] = self._p2p.describe()
+        return d
+
     def run(self, n_steps: Optional[int] = None) -> np.ndarray:
         """The timed region of the reference (`d2q9-bgk.c:278-398`): step loop + av_vels reduction."""
         n = self.params.max_iters if n_steps is None else n_steps
         if not self._partitioned:
             return self.partition.run(n)
-        if self._ring is not None:
-            tot = self._ring.run(n)
+        if self._p2p is not None or self._ring is not None:
+            tot = (self._p2p or self._ring).run(n)
             return (tot * np.float64(self.free_cells_inv)).astype(np.float32)          # :367
         import torch
         with torch.cuda.stream(self._stream):
@@ -503,43 +764,74 @@ class Simulation:
     def local_cells(self) -> np.ndarray:
         return self.partition.get_cells()
 
-    def gather_cells(self) -> Optional[np.ndarray]:
-        """Whole-grid AoS cells on rank 0 (None elsewhere) — what `write_values` serialises rank by rank."""
-        local = self.local_cells()
+    def _gather_rows(self, local: np.ndarray) -> Optional[np.ndarray]:
+        """Rank 0 gets the ranks' row blocks concatenated in rank order (None elsewhere) — the order in which
+        the reference's ranks append to final_state.dat (`d2q9-bgk.c:1049-1057`)."""
         if self.size == 1:
             return local
         import torch
         import torch.distributed as dist
-        if self._torch_device is None:
-            self._torch_device = torch.device("cuda", self.device)
-        if dist.get_backend(self.exchange.group) == "gloo":
-            self._gather_device = torch.device("cpu")
-        else:
-            self._gather_device = self._torch_device
-        mine = torch.from_numpy(local).to(self._gather_device)
+        group = self.exchange.group
+        on_host = dist.get_backend(group) == "gloo"
+        dev = torch.device("cpu") if on_host else torch.device("cuda", self.device)
+        mine = torch.from_numpy(local).to(dev)
         if self.rank == 0:
-            parts = [torch.empty((n, self.params.nx, _capi.NSPEEDS), dtype=torch.float32, device=self._gather_device)
-                     for n in self.ny_local]
+            parts = [torch.empty((n,) + tuple(local.shape[1:]), dtype=mine.dtype, device=dev) for n in self.ny_local]
             parts[0] = mine
             for r in range(1, self.size):
-                dist.recv(parts[r], src=self.exchange._global(r), group=self.exchange.group)
+                dist.recv(parts[r], src=self.exchange._global(r), group=group)
             return torch.cat(parts, dim=0).cpu().numpy()
-        dist.send(mine, dst=self.exchange._global(0), group=self.exchange.group)
+        dist.send(mine, dst=self.exchange._global(0), group=group)
         return None
 
-    def reynolds(self, cells: Optional[np.ndarray] = None) -> float:
-        """`calc_reynolds` on whole-grid cells (rank 0), reference order (`d2q9-bgk.c:707-757,1002-1008`)."""
-        cells = self.gather_cells() if cells is None else cells
-        tot_u = np.float32(av_velocity_host(self.params, cells, self.obstacles))
+    def gather_cells(self) -> Optional[np.ndarray]:
+        """Whole-grid AoS cells on rank 0 (None elsewhere)."""
+        return self._gather_rows(self.local_cells())
+
+    def gather_observables(self) -> Optional[np.ndarray]:
+        """Whole-grid (u_x, u_y, u, pressure) on rank 0 (None elsewhere): 4 floats per cell computed on the
+        device instead of the 9 populations (`d2q9-bgk.c:1084-1111`)."""
+        return self._gather_rows(self.partition.get_observables())
+
+    def _whole_map(self) -> np.ndarray:
+        if self.obstacles is None:
+            raise LbmError("the whole obstacle map lives on rank 0 only")
+        return self.obstacles
+
+    def reynolds(self, cells: Optional[np.ndarray] = None, *, observables: Optional[np.ndarray] = None) -> Optional[float]:
+        """`calc_reynolds` on the whole grid, reference order (`d2q9-bgk.c:707-757,1002-1008`).  Rank 0
+        returns the value; the other ranks of a distributed run take part in the gather and return None."""
+        if cells is None and observables is None:
+            observables = self.gather_observables()
+        if self.rank != 0:
+            return None
+        if observables is not None:
+            tot_u = np.float32(av_velocity_obs(self.params, observables, self._whole_map()))
+        else:
+            tot_u = np.float32(av_velocity_host(self.params, cells, self._whole_map()))
         return reynolds(self.params, float(tot_u * self.free_cells_inv))
 
-    def write_values(self, av_vels: np.ndarray, directory: str = ".", cells: Optional[np.ndarray] = None) -> None:
-        cells = self.gather_cells() if cells is None else cells
-        if self.rank == 0:
-            write_final_state(os.path.join(directory, "final_state.dat"), self.params, cells, self.obstacles)
-            write_av_vels(os.path.join(directory, "av_vels.dat"), av_vels)
+    def write_values(self, av_vels: np.ndarray, directory: str = ".", cells: Optional[np.ndarray] = None, *,
+                     observables: Optional[np.ndarray] = None) -> None:
+        """`write_values()` (`d2q9-bgk.c:1034-1143`): rank 0 writes both files; the other ranks only take part
+        in the gather (when neither cells nor observables are passed in)."""
+        if cells is None and observables is None:
+            observables = self.gather_observables()
+        if self.rank != 0:
+            return
+        path = os.path.join(directory, "final_state.dat")
+        if observables is not None:
+            write_final_state_obs(path, self.params, observables, self._whole_map())
+        else:
+            write_final_state(path, self.params, cells, self._whole_map())
+        write_av_vels(os.path.join(directory, "av_vels.dat"), av_vels)
 
     def close(self) -> None:
         if self._ring is not None:
             self._ring.close()
-        self.partition.close()
+            self._ring = None
+        if self._p2p is not None:
+            self._p2p.close()
+            self._p2p = None
+        if getattr(self, "partition", None) is not None:
+            self.partition.close()

@@ -1,18 +1,35 @@
 #!/bin/bash
-# One GPU-box session: parity suite, bench line, rocprofv3 kernel trace + HBM counters.
-# Usage (from the repo root, via gpurun): bash scripts/gpu_round.sh <tag>
+# One GPU-box session: parity suite, bench line, rocprofv3 kernel trace + the PMC passes behind the roofline line.
+# Usage (from the repo root, via gpurun): bash scripts/gpu_round.sh <tag> [skip-tests]
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest_gpu_$TAG.log; cat $OUT/pytest_gpu_$TAG.log
-grep -q "passed" $OUT/pytest_gpu_$TAG.log
+if [ "$2" != "skip-tests" ]; then
+  timeout -k 10 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_$TAG.log 2>&1 || (tail -40 $OUT/pytest_gpu_$TAG.log; exit 1)
+  tail -5 $OUT/pytest_gpu_$TAG.log
+fi
 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || (cat $OUT/bench_$TAG.err; exit 1)
-cat $OUT/bench_$TAG.json
+cat $OUT/bench_$TAG.json | cut -c1-400
+# the driver's own invocation: short timed region
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_style_$TAG.json 2>> $OUT/bench_$TAG.err
+cat $OUT/bench_driver_style_$TAG.json | cut -c1-200
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 100 --warmup 10 > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 2 > /dev/null 2> $OUT/pmc_fetch_$TAG.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 2 > /dev/null 2> $OUT/pmc_write_$TAG.err
-find $OUT -name "*.csv" | head -20
+B="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --reps 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $B --steps 100 --warmup 10 > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err
+echo trace done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -o pmc -- python3 $B --steps 18 --warmup 3 > /dev/null 2> $OUT/pmc_${TAG}_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write -o pmc -- python3 $B --steps 18 --warmup 3 > /dev/null 2> $OUT/pmc_${TAG}_write.err
+echo hbm passes done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${TAG}_sq1 -o pmc -- python3 $B --steps 18 --warmup 3 > /dev/null 2> $OUT/pmc_${TAG}_sq1.err
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_${TAG}_sq2 -o pmc -- python3 $B --steps 18 --warmup 3 > /dev/null 2> $OUT/pmc_${TAG}_sq2.err
+echo sq passes done
+cd $GRAFT_REPO_ROOT
+python scripts/make_roofline.py $TAG $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/pmc_${TAG}_sq1 $OUT/pmc_${TAG}_sq2 | tail -30
+mkdir -p $OUT/profiles_$TAG && cp -r profiles/$TAG/* $OUT/profiles_$TAG/
+find $OUT/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/profiles_$TAG/kernel_stats_bench_8192.csv \;
+cp $OUT/bench_$TAG.json $OUT/profiles_$TAG/bench_n1.json
+cp $OUT/bench_driver_style_$TAG.json $OUT/profiles_$TAG/bench_n1_driver_style.json

@@ -459,22 +459,27 @@ def test_tile_kernel_shapes_and_step_counts(lbm, oracle, monkeypatch, geom, nx, 
     s.close()
 
 
-@pytest.mark.parametrize("ranks,name", [(2, "128x256_t2000"), (3, "256x256_t1000")])
-def test_several_ranks_share_the_gpu_over_gloo(lbm, digests, tmp_path, ranks, name):
+@pytest.mark.parametrize("ranks,name,exchange", [(2, "128x256_t2000", "torch"), (3, "256x256_t1000", "torch"),
+                                                 (2, "256x256_t1000", "p2p"), (3, "1024x1024_t200", "p2p")])
+def test_several_ranks_share_the_gpu_over_gloo(lbm, digests, tmp_path, ranks, name, exchange):
     """The multi-process row-partitioned run end to end — torchrun, one process per rank, each with
-    its own HIP partition, neighbour exchange, final reduction, rank-0 gather and output — on ONE GPU:
-    RCCL refuses ranks that share a device, so the halos are staged through the host and carried by
-    gloo here (HaloExchange.host_staged); everything else is the N-GPU code path."""
+    its own HIP partition, neighbour exchange, final reduction, rank-0 gather and output — on ONE GPU.
+    RCCL refuses ranks that share a device, so the process group is gloo and the halos travel either
+    staged through the host ("torch": HaloExchange.host_staged, one-step loop) or by the native
+    peer-to-peer loop ("p2p": every rank maps its neighbours' grids with hipIpcOpenMemHandle and stores
+    its edge rows into their ghost rows — the N-GPU code path except for the xGMI wire).  Only rank 0
+    parses the files; the obstacle rows are scattered."""
     import sys
     from conftest import ROOT
     ppath, opath = deck_paths(name, digests)
-    env = dict(os.environ, LBM_FORCE_DEVICE="0", LBM_DIST_BACKEND="gloo")
+    env = dict(os.environ, LBM_FORCE_DEVICE="0", LBM_DIST_BACKEND="gloo", LBM_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = [l for l in r.stdout.splitlines() if l.strip()]
     assert out[out.index("==done==") + 1] == digests[name]["reynolds_line"]
+    assert f"{exchange} loop" in [l for l in out if l.startswith("MLUPS")][0]
     assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
     av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
@@ -807,3 +812,219 @@ def test_full_1024_deck_as_a_k_step_ring_matches_the_reference_file(lbm, digests
     assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
     steps = np.asarray(digests[name]["av_sample_steps"])
     assert np.allclose(av[steps], digests[name]["av_sample_values"], rtol=4e-3)
+
+
+# ---- peer-to-peer halo transport (include/lbm_d2q9_p2p.h) ---------------------------------------------
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+@pytest.mark.parametrize("schedule", ["edge", "serial"])
+@pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 61), ("128x128", 50), ("1024x1024_t200", 31)])
+def test_p2p_ring_of_one(lbm, oracle, digests, monkeypatch, name, steps, K, schedule):
+    """The peer-to-peer loop on a 1-rank ring: the rank pushes its edge rows into its OWN ghost rows and
+    raises its own flags — push kernel, flag protocol, wait kernels, both schedules, repeated runs, step
+    counts K does not divide, the all-gather reduction with one contributor."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    monkeypatch.setenv("LBM_P2P_SCHEDULE", schedule)
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="p2p", strict=True)
+    assert sim.loop == "p2p" and sim.partition.macro_steps == K and schedule.split()[0] in sim.describe()["p2p"]
+    av = np.concatenate([sim.run(steps), sim.run(5), sim.run(1)])
+    cells = sim.local_cells()
+    sim.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps + 6, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+P2P_CASES = {
+    2: [dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11]), dict(nx=192, ny=99, K=3, schedule="serial", runs=[7, 24]),
+        dict(nx=512, ny=70, K=2, schedule="edge", runs=[31], scatter=True), dict(nx=1024, ny=1024, K=0, schedule="", runs=[13, 2], walls=True),
+        dict(nx=256, ny=64, K=1, schedule="serial", runs=[9])],
+    3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
+        dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True)],
+    4: [dict(nx=256, ny=131, K=3, schedule="edge", runs=[31]), dict(nx=128, ny=260, K=4, schedule="serial", runs=[17, 14]),
+        dict(nx=2048, ny=4100, K=0, schedule="", runs=[7], scatter=True, p=0.005)],
+}
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 4])
+def test_p2p_ranks_in_separate_processes_share_the_gpu(lbm, ranks):
+    """The peer-to-peer loop as an N-GPU run executes it — one process per rank, each mapping its neighbours'
+    grids with hipIpcOpenMemHandle — with the ranks sharing this box's one GPU (tests/p2p_worker.py).  Uneven row
+    counts (the reference's decomposition gives 34, 33, 33 rows for ny = 100 on 3 ranks), neighbours with
+    different plane strides, south == north (2 ranks), tile rows that stick out, both schedules, repeated runs
+    with step counts K does not divide, the obstacle scatter, the rank-order reduction, the additive digest."""
+    import json
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBM_P2P_TIMEOUT_MS="20000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), json.dumps(P2P_CASES[ranks])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
+    assert r.returncode == 0 and len(lines) == len(P2P_CASES[ranks]) and all(" ok " in l for l in lines), (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge")])
+def test_p2p_partitions_in_one_process(lbm, oracle, monkeypatch, nx, ny, size, K, schedule):
+    """Several ranks of one run as contexts of ONE process (one host thread per rank, as a single-process
+    multi-GPU host drives them), connected through plain pointers instead of IPC handles."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    monkeypatch.setenv("LBM_P2P_SCHEDULE", schedule)
+    monkeypatch.setenv("LBM_P2P_TIMEOUT_MS", "10000")
+    steps = 31
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 5 + ny, False)
+    free = lbm.count_free_cells(obst)
+    lays = [lbm.rank_layout(p, size, r) for r in range(size)]
+    assert all(l["macro_k"] == K for l in lays), lays
+    parts = [lbm.Partition(p, free, lbm.obstacle_window(obst, lays[r]), rank_of=(r, size)) for r in range(size)]
+    rings = lbm.P2PRing.local_ring(parts)
+    a = lbm.P2PRing.run_all(rings, 20)
+    b = lbm.P2PRing.run_all(rings, 11)
+    for r in range(1, size):                                    # the reduction is bitwise the same on every rank
+        assert np.array_equal(a[r], a[0]) and np.array_equal(b[r], b[0])
+    cells = np.concatenate([q.get_cells() for q in parts], axis=0)
+    for ring in rings:
+        ring.close()
+    for q in parts:
+        q.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    av = np.concatenate([a[0], b[0]]) * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+
+
+def test_p2p_refuses_ranks_with_different_layouts(lbm, monkeypatch):
+    """Ranks created with different K (what per-rank decisions gave for uneven partitions) are turned away at
+    connect with an error — not left to hang in the first exchange."""
+    p = lbm.Params(256, 128, 10, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(256, 128, 0.03, 3, False)
+    free = lbm.count_free_cells(obst)
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "3")
+    a = lbm.Partition(p, free, obst[:64], 0, obstacles_global=obst)
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "2")
+    b = lbm.Partition(p, free, obst[64:], 64, obstacles_global=obst)
+    assert (a.macro_steps, b.macro_steps) == (3, 2)
+    with pytest.raises(lbm.LbmError, match="different layout"):
+        lbm.P2PRing.local_ring([a, b])
+    a.close(); b.close()
+
+
+def test_p2p_missing_peer_is_an_error_not_a_hang(lbm, monkeypatch):
+    """A rank whose neighbour never starts the run gives up after the time-out with an error."""
+    monkeypatch.setenv("LBM_P2P_TIMEOUT_MS", "300")
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "3")
+    p = lbm.Params(256, 128, 10, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(256, 128, 0.03, 3, False)
+    free = lbm.count_free_cells(obst)
+    parts = [lbm.Partition(p, free, lbm.obstacle_window(obst, lbm.rank_layout(p, 2, r)), rank_of=(r, 2)) for r in range(2)]
+    rings = lbm.P2PRing.local_ring(parts)
+    with pytest.raises(lbm.LbmError, match="did not arrive in time"):
+        rings[0].run(6)                                         # rank 1 never runs
+    for ring in rings:
+        ring.close()
+    for q in parts:
+        q.close()
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
+    """`python bench.py --gpus 2` as the driver calls it (no rank environment): the parent starts two rank
+    processes, they share this box's one GPU (gloo group, peer-to-peer halos over hipIpc), check themselves
+    bit for bit against a single-GPU run, and ONE JSON line comes back saying what ran."""
+    import json
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LBM_FORCE_DEVICE="0", LBM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--reps", "3",
+                        "--workload", "2048x2048"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0
+    assert out["config"]["loop"] == "p2p" and out["config"]["macro_k"] == 3 and "ipc" in out["config"]["p2p"]
+    assert out["parity_check"]["ok"] is True and out["exchange_attempts"][0] == {"exchange": "p2p", "ok": True}
+    assert out["launch_attempts"][0]["returncode"] == 0
+
+
+def test_observables_path_writes_the_reference_file(lbm, digests, tmp_path):
+    """lbm_get_observables (4 floats per cell computed on the device) + lbm_write_final_state_obs /
+    lbm_av_velocity_obs against the 9-population path: same bytes, same Reynolds line; also on a random state
+    with a zero-density cell (NaN columns)."""
+    name = "256x256_t1000"
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst)
+    av = sim.run()
+    obs = sim.gather_observables()
+    assert "Reynolds number:\t\t%.12E" % sim.reynolds(observables=obs) == digests[name]["reynolds_line"]
+    sim.write_values(av, str(tmp_path), observables=obs)
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    sim.close()
+    rng = np.random.default_rng(3)
+    q = lbm.Params(48, 20, 8, 4, 0.1, 0.02, 1.6)
+    o2 = lbm.synthetic_obstacles(48, 20, 0.08, 9, False)
+    o2[0, :4] = 0
+    cells0 = (rng.random((20, 48, 9), dtype=np.float32) * 0.02 + 0.004).astype(np.float32)
+    cells0[0, 0] = 0.0                                            # rho = 0: NaN u_x, u_y, u (the reference prints -NAN)
+    cells0[0, 1] = [1e-45, 0, 0, 0, 0, 0, 0, 0, 0]
+    cells0[0, 2] = [-1.0, 0.5, 0, 0, 0, 0, 0, 0, 0]
+    part = lbm.Partition(q, lbm.count_free_cells(o2), o2)
+    part.set_cells(cells0)
+    a, b = str(tmp_path / "a.dat"), str(tmp_path / "b.dat")
+    lbm.write_final_state(a, q, cells0, o2)
+    lbm.write_final_state_obs(b, q, part.get_observables(), o2)
+    part.close()
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_av_velocity_sum_on_a_k_step_partition_with_unaligned_ghost_rows(lbm, monkeypatch):
+    """nx = 130, K = 3 puts the first owned cell at bit 390 of the obstacle bitfield (not a
+    multiple of 32); lbm_av_velocity_sum must test the owned cells' own bits."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "3")
+    p = lbm.Params(130, 40, 30, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(130, 40, 0.2, 17, False)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="p2p", strict=True)
+    assert sim.partition.macro_steps == 3
+    sim.run(30)
+    host = lbm.av_velocity_host(p, sim.local_cells(), obst)
+    dev = sim.partition.av_velocity_sum()
+    sim.close()
+    assert abs(dev - host) / host < 1e-5
+
+
+@pytest.mark.parametrize("K", [0, 3])
+def test_rccl_ring_with_one_all_reduce_per_step(lbm, oracle, digests, monkeypatch, K):
+    """The measured mode of north_star's wording: every (macro-)step's totals folded at once and all-reduced
+    on the compute stream, the next step behind it.  Same results as the hoisted reduction."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl", strict=True, step_allreduce=True)
+    assert sim.describe()["step_allreduce"] and sim.describe()["rccl_nranks"] == 1 and sim.partition.macro_steps == K
+    av = np.concatenate([sim.run(41), sim.run(7)])
+    cells = sim.local_cells()
+    sim.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 48, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+def test_rank_partitions_from_windows_only(lbm, oracle, monkeypatch):
+    """lbm_create_rank: a rank is built from its obstacle WINDOW alone (owned rows + ghost rows); in-process
+    exchange by device copies as in the other K-step partition tests."""
+    nx, ny, size, steps = 256, 200, 3, 25
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.05, 77, True)
+    free = lbm.count_free_cells(obst)
+    parts = [lbm.Partition(p, free, lbm.obstacle_window(obst, lbm.rank_layout(p, size, r)), rank_of=(r, size)) for r in range(size)]
+    K = parts[0].macro_steps
+    assert K == 4 and all(q.macro_steps == K for q in parts)
+    sums = _k_step_partitions_in_process(lbm, parts, steps, K)
+    cells = np.concatenate([q.get_cells() for q in parts], axis=0)
+    for q in parts:
+        q.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    av = sums * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12

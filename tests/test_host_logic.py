@@ -22,14 +22,58 @@ def test_library_exports_every_declared_symbol(lbm):
     assert declared <= exported, declared - exported
     assert declared == set(lbm.EXPORTS), declared ^ set(lbm.EXPORTS)
     lib = lbm.load_library()
-    assert lib.lbm_abi_version() == 1
+    assert lib.lbm_abi_version() == 2
+
+
+def test_p2p_entry_points_are_exported_by_the_core_library(lbm):
+    header = open(os.path.join(ROOT, "include", "lbm_d2q9_p2p.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lbm_p2p_[a-z_0-9]+)\s*\(", header))
+    assert declared == {"lbm_p2p_create", "lbm_p2p_handle", "lbm_p2p_connect", "lbm_p2p_destroy", "lbm_p2p_run", "lbm_p2p_describe"}
+    nm = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert declared <= set(re.findall(r" T (lbm_[a-z_0-9]+)", nm))
+    assert declared == set(lbm.P2P_EXPORTS)
+    # no communication library behind it: the core library does not link RCCL
+    needed = subprocess.run(["readelf", "-d", lbm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed.lower()
+
+
+def test_headers_are_c99(lbm, tmp_path):
+    """north_star asks for a thin C host: the three headers must compile as C (gcc -std=c99 -pedantic) and a C
+    caller must link against the library and get an answer from the host-only half."""
+    src = tmp_path / "caller.c"
+    src.write_text('''
+#include <stdio.h>
+#include "lbm_d2q9.h"
+#include "lbm_d2q9_p2p.h"
+#include "lbm_d2q9_rccl.h"
+int main(void)
+{
+  int ny_local[3], displs[3];
+  lbm_params p = {1024, 190, 10, 10, 0.1f, 0.005f, 1.85f};
+  lbm_layout lay;
+  if (lbm_abi_version() != LBM_ABI_VERSION) return 2;
+  if (lbm_decompose(10, 3, ny_local, displs)) return 3;
+  if (lbm_rank_layout(&p, 6, 5, LBM_FLAG_DEFAULT, &lay)) return 4;
+  printf("%d %d %d | %d %d %d\\n", ny_local[0], ny_local[1], ny_local[2], lay.y0, lay.ny_local, lay.macro_k);
+  return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-L",
+                        os.path.dirname(lbm.LIB_PATH), "-llbm_d2q9", f"-Wl,-rpath,{os.path.dirname(lbm.LIB_PATH)}", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == "4 3 3 | 159 31 0\n", (r.returncode, r.stdout, r.stderr)
 
 
 def test_rccl_library_exports_every_declared_symbol(lbm):
     header = open(os.path.join(ROOT, "include", "lbm_d2q9_rccl.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(lbm_comm_[a-z_0-9]+)\s*\(", header))
-    assert declared == {"lbm_comm_unique_id", "lbm_comm_create", "lbm_comm_destroy", "lbm_comm_run"}
+    assert declared == {"lbm_comm_unique_id", "lbm_comm_create", "lbm_comm_destroy", "lbm_comm_run", "lbm_comm_nranks",
+                        "lbm_comm_set_step_allreduce"}
     nm = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_RCCL_PATH], capture_output=True, text=True, check=True).stdout
     assert declared <= set(re.findall(r" T (lbm_[a-z_0-9]+)", nm))
     assert declared == set(lbm.RCCL_EXPORTS)
@@ -110,6 +154,64 @@ def test_decompose_follows_the_reference_rule(lbm, oracle):
     assert lbm.decompose(128, 64)[0][-2:] == [1, 3]
 
 
+def test_rank_layout_is_one_decision_for_all_ranks(lbm):
+    """K-step mode and K must not be decided per rank.  Uneven decompositions
+    (ny = 190 on 6 ranks: 32,32,32,32,31,31; ny = 127 on 4: 32,32,32,31) and partitions straddling the
+    K = 3 / K = 4 size threshold give every rank the same answer."""
+    for nx, ny, size in [(1024, 190, 6), (1024, 127, 4), (8192, 8192, 8), (1024, 1024, 8), (2048, 2049, 2), (8192, 515, 2),
+                         (130, 100, 3), (126, 400, 4), (8192, 8192, 1), (4096, 1000, 7)]:
+        p = lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
+        lays = [lbm.rank_layout(p, size, r) for r in range(size)]
+        nyl, dis = lbm.decompose(ny, size)
+        assert [l["ny_local"] for l in lays] == nyl and [l["y0"] for l in lays] == dis
+        assert len({l["macro_k"] for l in lays}) == 1, lays
+        assert all(l["ghost"] == l["macro_k"] for l in lays)
+        k = lays[0]["macro_k"]
+        if size == 1:
+            assert k == 0                                            # a whole periodic grid needs no ghost rows ...
+            assert lbm.rank_layout(p, 1, 0, lbm._capi.FLAG_FORCE_HALO)["macro_k"] == (3 if nx * ny >= 1 << 21 else 4)   # ... a 1-rank ring does
+        elif min(nyl) < 32 or nx % 2 or nx < 128 and nx % 64:
+            assert k == 0                                            # one ineligible rank puts EVERY rank in one-step mode
+        else:
+            assert k == (4 if nx * max(nyl) < 1 << 21 else 3)
+        assert all(l["macro_k"] == 0 for l in (lbm.rank_layout(p, size, r, lbm._capi.FLAG_ONE_STEP) for r in range(size)))
+    p = lbm.Params(1024, 190, 10, 10, 0.1, 0.005, 1.85)
+    assert [lbm.rank_layout(p, 6, r)["macro_k"] for r in range(6)] == [0] * 6       # ranks 4, 5 own 31 rows
+    with pytest.raises(lbm.LbmError):
+        lbm.rank_layout(p, 6, 6)
+
+
+def test_obstacle_window_wraps_periodically(lbm):
+    obst = np.arange(12 * 4, dtype=np.int32).reshape(12, 4)
+    w = lbm.obstacle_window(obst, {"y0": 0, "ny_local": 5, "ghost": 2})
+    assert w.shape == (9, 4) and np.array_equal(w[:, 0] // 4, [10, 11, 0, 1, 2, 3, 4, 5, 6])
+    w = lbm.obstacle_window(obst, {"y0": 8, "ny_local": 4, "ghost": 3})
+    assert np.array_equal(w[:, 0] // 4, [5, 6, 7, 8, 9, 10, 11, 0, 1, 2])
+    assert np.array_equal(lbm.obstacle_window(obst, {"y0": 3, "ny_local": 2, "ghost": 0}), obst[3:5])
+
+
+def test_observables_writer_and_reynolds_equal_the_cells_path(lbm, oracle, tmp_path):
+    """lbm_write_final_state_obs / lbm_av_velocity_obs on (u_x, u_y, u, pressure) computed as the device
+    kernel computes them must give the bytes / the float of the 9-population path."""
+    rng = np.random.default_rng(7)
+    p = lbm.Params(24, 10, 3, 7, 0.1, 0.005, 1.3)
+    cells = (rng.random((10, 24, 9), dtype=np.float32) * 0.02 + 0.005).astype(np.float32)
+    obst = (rng.random((10, 24)) < 0.2).astype(np.int32)
+    f = cells
+    rho = np.zeros(cells.shape[:2], np.float32)
+    for k in range(9):
+        rho = rho + f[..., k]
+    ux = (f[..., 1] + f[..., 5] + f[..., 8] - (f[..., 3] + f[..., 6] + f[..., 7])) / rho
+    uy = (f[..., 2] + f[..., 5] + f[..., 6] - (f[..., 4] + f[..., 7] + f[..., 8])) / rho
+    u = np.sqrt((ux * ux + uy * uy).astype(np.float64)).astype(np.float32)
+    obs = np.stack([ux, uy, u, rho * np.float32(1.0 / 3.0)], axis=-1).astype(np.float32)
+    a, b = str(tmp_path / "a.dat"), str(tmp_path / "b.dat")
+    lbm.write_final_state(a, p, cells, obst, displ=3)
+    lbm.write_final_state_obs(b, p, obs, obst, displ=3)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert lbm.av_velocity_obs(p, obs, obst) == lbm.av_velocity_host(p, cells, obst) == oracle.av_velocity_sum(p, cells, obst)
+
+
 def test_writers_and_epilogue_match_the_oracle(lbm, oracle, tmp_path):
     rng = np.random.default_rng(5)
     p = lbm.Params(16, 6, 3, 7, 0.1, 0.005, 1.3)
@@ -181,8 +283,29 @@ def test_front_ends_parse_arguments_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "d2q9_bgk.py")], capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr.startswith("Usage: ") and r.stderr.rstrip().endswith("<paramfile> <obstaclefile>")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "d2q9_bgk.py"), "/nonexistent.params", "x"], capture_output=True, text=True)
-    assert r.returncode == 1 and "could not open input parameter file: /nonexistent.params" in r.stderr
+    assert r.returncode == 1                                           # die() format of d2q9-bgk.c:1145-1151
+    assert re.fullmatch(r"Error at line \d+ of file d2q9_bgk\.py:\ncould not open input parameter file: /nonexistent.params\n", r.stderr)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
     r = subprocess.run([sys.executable, os.path.join(ROOT, "check", "check.py"), "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--ref-av-vels-file" in r.stdout
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_starts_its_own_rank_processes(n):
+    """`python bench.py --gpus N` outside torch.distributed.run (how the driver calls it) must start N fresh
+    rank processes itself, before anything touches the GPU, and relay ONE JSON line.  --dry-launch makes the
+    ranks rendezvous over gloo and report themselves instead of running the GPU path."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_launch"] is True and out["n_gpus"] == n
+    assert sorted(d["rank"] for d in out["ranks"]) == list(range(n)) and all(d["world"] == n for d in out["ranks"])
+    assert len({d["pid"] for d in out["ranks"]}) == n and os.getpid() not in {d["pid"] for d in out["ranks"]}
+    assert out["launch_attempts"][0]["returncode"] == 0
