@@ -14,7 +14,8 @@ namespace {
 
 struct P2PWindowHeader {                 // start of every rank's exported window (uncached device memory)
   unsigned long long halo_flag[2];       // [0]: epoch of the rows my SOUTH neighbour pushed into my bottom ghost rows; [1]: NORTH
-  unsigned long long halo_parity[2];     // the pusher's grid parity for that epoch (lock-step check)
+  unsigned long long halo_parity[4];     // [2*dir + (epoch & 1)]: the pusher's grid parity for that epoch (lock-step check).  A pusher
+                                         // may run ONE epoch ahead of the waiter, never two: a slot per epoch parity is not overwritten early
   unsigned long long reduce_flag[64];    // [r]: rank r's sums of reduce round N are in my slot r
 };
 constexpr size_t kP2PHeaderBytes = 4096;
@@ -70,7 +71,8 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
 // One wave: wait until every one of `nflags` flag words has reached `epoch` (acquire, system scope), at
 // most `timeout_ticks` of the 100 MHz wall clock; on time-out set *err (host-visible) to 1 + the index of
 // the missing flag.  With *err already set the kernel returns at once, so a failed run drains quickly.
-// parity_words (may be null): the pushers' grid parity must equal `parity` (ranks run in lock step).
+// parity_words (may be null; two per flag, indexed by the epoch's parity): the pushers' grid parity must equal
+// `parity` (ranks run in lock step).
 __global__ void __launch_bounds__(64) lbm_p2p_wait_kernel(const unsigned long long* flags, const unsigned long long* parity_words, int nflags,
                                                            unsigned long long epoch, unsigned long long parity, long long timeout_ticks, int* err)
 {
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(64) lbm_p2p_wait_kernel(const unsigned long lo
       }
       __builtin_amdgcn_s_sleep(32);
     }
-    if (parity_words && __hip_atomic_load(parity_words + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
+    if (parity_words && __hip_atomic_load(parity_words + 2 * f + (epoch & 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
       __hip_atomic_store(err, 100 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }

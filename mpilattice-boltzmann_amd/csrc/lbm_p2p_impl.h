@@ -105,8 +105,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
   a.nfloats = K * nx;
   a.flag[0] = &header_of(ps.window)->halo_flag[1];       // my rows arrive from the south neighbour's NORTH
   a.flag[1] = &header_of(pn.window)->halo_flag[0];
-  a.parity_word[0] = &header_of(ps.window)->halo_parity[1];
-  a.parity_word[1] = &header_of(pn.window)->halo_parity[0];
+  a.parity_word[0] = &header_of(ps.window)->halo_parity[2 * 1 + (epoch & 1ull)];
+  a.parity_word[1] = &header_of(pn.window)->halo_parity[2 * 0 + (epoch & 1ull)];
   a.epoch = epoch;
   a.parity = static_cast<unsigned long long>(g);
   a.done = t->done;
@@ -259,6 +259,10 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
       for (int g = 0; g < 2; ++g) p.grid_alloc[g] = c->grid_alloc[g];
       p.window = t->window;
     } else if (b.pid == me) {                                  // another context of this process: plain pointers
+      // Ranks of one process on ONE device share that process's few hardware queues: a wait kernel could end
+      // up in front of the very push it waits for.  One stream per rank keeps that from happening in practice
+      // (the single-process host is meant for one rank per GPU, where the question does not arise).
+      if (b.device == c->device) t->edge_stream = false;
       if (b.device != c->device) {
         hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {

@@ -868,7 +868,9 @@ def test_p2p_ranks_in_separate_processes_share_the_gpu(lbm, ranks):
 @pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge")])
 def test_p2p_partitions_in_one_process(lbm, oracle, monkeypatch, nx, ny, size, K, schedule):
     """Several ranks of one run as contexts of ONE process (one host thread per rank, as a single-process
-    multi-GPU host drives them), connected through plain pointers instead of IPC handles."""
+    multi-GPU host drives them), connected through plain pointers instead of IPC handles.  Ranks of one
+    process that share a DEVICE run the serial schedule whatever was asked for: their streams share the
+    process's few hardware queues, and a wait kernel must never sit in front of the push it waits for."""
     monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
     monkeypatch.setenv("LBM_P2P_SCHEDULE", schedule)
     monkeypatch.setenv("LBM_P2P_TIMEOUT_MS", "10000")
