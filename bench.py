@@ -437,14 +437,16 @@ def main() -> int:
         if pmc is not None:
             hbm_gbs = pmc["hbm_bytes_per_launch"] / avg_launch_s / 1e9
             frac_hbm = hbm_gbs / HBM_PEAK_GBS
-            clock_hz = pmc.get("clock_hz", 2.4e9)
-            frac_valu = pmc["valu_busy_cycles_per_launch"] / (avg_launch_s * clock_hz * pmc.get("simds", 1024))
+            # VALU: busy cycles over available cycles, both counted in ONE profiled pass (4 x SQ_ACTIVE_INST_VALU over
+            # GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): a ratio of cycles, so it does not depend on the clock the chip
+            # holds (profiled passes run ~8 % slower than this un-profiled run, at a lower clock)
+            frac_valu = pmc["frac_valu_profiled"]
             roof.update({"traffic": pmc["hbm_bytes_per_launch"], "frac_hbm_physical": frac_hbm, "frac_valu": frac_valu,
                          "bound": "hbm" if frac_hbm >= frac_valu else "valu", "achieved": hbm_gbs, "frac": max(frac_hbm, frac_valu),
                          "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"), "pmc_source": pmc.get("source"),
                          "note": "achieved/traffic = physical HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate "
-                                 "passes) over this run's launch time; frac_valu = SQ_ACTIVE_INST_VALU busy cycles per launch over "
-                                 "launch time x clock x 1024 SIMDs; frac = the larger (the binding limit)"})
+                                 "passes) over this run's launch time; frac_valu = 4 x SQ_ACTIVE_INST_VALU busy cycles per launch over "
+                                 "the cycles of the same profiled pass x 1024 SIMDs (a cycle ratio); frac = the larger (the binding limit)"})
         else:
             roof.update({"achieved": algo_gbs, "frac": None,
                          "note": "no PMC summary for this kernel/workload in profiles/r02/roofline.json: only the 108-B convention figure"})

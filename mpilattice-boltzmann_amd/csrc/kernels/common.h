@@ -244,6 +244,11 @@ __device__ __forceinline__ auto& at_byte(B* base, uint32_t byte_off)
 // ghost ring: they do not count, and the double-precision sqrt is a tenth of the cell's instructions).
 // tile_accel is block-uniform: false for the tiles whose frame does not meet row ny-2, which then skip
 // the accelerate_flow code instead of predicating it away in every pair.
+// FAST (LBM_FLAG_FAST_AVVELS, multi kernel only): the sum|u| term of a cell is formed in float — v_sqrt_f32
+// and one multiply instead of the ~20 double-precision instructions of sqrt((double)msq) * (double)rinv — and
+// widened for the double tree sum.  Populations are untouched; av_vels then agrees with the exact-term form to
+// ~1e-9 instead of 1e-15 (tests: 1e-6 against the oracle's exact sum, check.py's 1 % against the goldens).
+template <bool FAST = false>
 __device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
                                               uint32_t skip, f2 (&out)[9])
 {
@@ -274,9 +279,15 @@ __device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, 
   }
   double term = 0.0;
   if (skip != 3u) {
-    const double t0 = sqrt_of_float(msq.x) * static_cast<double>(rinv.x);   // :667
-    const double t1 = sqrt_of_float(msq.y) * static_cast<double>(rinv.y);
-    term = ((skip & 1u) ? 0.0 : t0) + ((skip & 2u) ? 0.0 : t1);
+    if constexpr (FAST) {
+      const f2 root = f2{__builtin_amdgcn_sqrtf(msq.x), __builtin_amdgcn_sqrtf(msq.y)};
+      const f2 tf = root * rinv;
+      term = static_cast<double>(((skip & 1u) ? 0.0f : tf.x) + ((skip & 2u) ? 0.0f : tf.y));
+    } else {
+      const double t0 = sqrt_of_float(msq.x) * static_cast<double>(rinv.x);   // :667
+      const double t1 = sqrt_of_float(msq.y) * static_cast<double>(rinv.y);
+      term = ((skip & 1u) ? 0.0 : t0) + ((skip & 2u) ? 0.0 : t1);
+    }
   }
   return term;
 }

@@ -65,7 +65,7 @@ struct MultiArgs {
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
-template <int K>
+template <int K, bool FAST>   // FAST: float sum|u| terms (LBM_FLAG_FAST_AVVELS), see finish_pair
 __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K>;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
                          (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
-      acc[0] += finish_pair(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out);
+      acc[0] += finish_pair<FAST>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
           p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
           const bool owned = lane_on && (fl & 4u);
-          const double term = finish_pair(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
+          const double term = finish_pair<FAST>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
                                           owned ? (fl & 3u) : 3u, outs);
 #pragma unroll
           for (int m = 1; m < K; ++m)

@@ -3,10 +3,10 @@
 // Part of the single translation unit lbm_kernels.hip (device code of liblbm_d2q9.so, gfx950 only).
 //
 // Memory-model notes (gfx950): a peer GPU's memory is reached over xGMI through this GPU's L2, so what is
-// meant for the peer is written with system-scope stores (write-through, `sc0 sc1`) and followed by a
-// system-scope release fence before the flag; flags live in an uncached window and are read / written with
-// system-scope atomics; the consumer's data loads happen in a LATER kernel of its stream (kernel boundaries
-// invalidate the non-coherent caches, as they must between any two launches that hand data across XCDs).
+// meant for the peer is followed by a system-scope release fence (L2 write-back) before the flag is raised;
+// flags live in an uncached window and are read / written with system-scope atomics; the consumer's data loads
+// happen in a LATER kernel of its stream (kernel boundaries invalidate the non-coherent caches, as they must
+// between any two launches that hand data across XCDs).
 #pragma once
 #include "common.h"
 
@@ -20,13 +20,6 @@ struct P2PWindowHeader {                 // start of every rank's exported windo
 };
 constexpr size_t kP2PHeaderBytes = 4096;
 static_assert(sizeof(P2PWindowHeader) <= kP2PHeaderBytes, "window header");
-
-__device__ __forceinline__ void store_system(float* p, f2 v)
-{
-  static_assert(sizeof(f2) == sizeof(unsigned long long), "f2 is 8 bytes");
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 struct P2PPushArgs {
   const float* src;                      // my grid (plane 0, storage row 0)
@@ -43,21 +36,27 @@ struct P2PPushArgs {
 
 // My first K owned rows -> the south neighbour's top ghost rows, my last K owned rows -> the north
 // neighbour's bottom ghost rows (all 9 planes), then the two epoch flags, raised by the last block to
-// finish.  grid = (ceil(nfloats/2/256), 9, 2).
+// finish.  A few large blocks (grid-stride over 2 directions x 9 planes x K*nx/2 float2's): the release towards
+// the peer is one L2 write-back per BLOCK — every wave's stores have left the CU at the barrier (vmcnt(0)), all
+// waves of a block sit on one XCD, so thread 0's system-scope fence covers them — and a write-back per wave of
+// an 864-block form of this kernel cost 50 us beside the interior launch instead of 8.
+constexpr int kP2PPushBlocks = 64;
+
 __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, int nx)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // float2 index within one plane's K rows (nx even)
-  const int plane = blockIdx.y, dir = blockIdx.z;
-  if (i * 2 < a.nfloats) {
+  const int per_plane = a.nfloats / 2;                         // float2's of one plane's K rows (nx even)
+  const int total = per_plane * 18;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < total; w += gridDim.x * 256) {
+    const int seg = w / per_plane, i = w - seg * per_plane;
+    const int dir = seg / 9, plane = seg - dir * 9;
     const f2 v = *reinterpret_cast<const f2*>(a.src + plane * a.ps + a.src_row[dir] * nx + static_cast<size_t>(i) * 2);
-    store_system(a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * 2, v);
+    *reinterpret_cast<f2*>(a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * 2) = v;
   }
-  __threadfence_system();                                      // this lane's rows are on their way before ...
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+    __threadfence_system();                                    // this block's rows are on their way before ...
     const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == total - 1) {                                   // ... the last block raises the flags
+    if (prev == gridDim.x - 1) {                               // ... the last block raises the flags
       __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       for (int d = 0; d < 2; ++d) {
@@ -100,10 +99,9 @@ __global__ void __launch_bounds__(64) lbm_p2p_wait_kernel(const unsigned long lo
 __global__ void __launch_bounds__(256) lbm_p2p_gather_kernel(const double* sums, int n, double* const* slots)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slots[blockIdx.y] + i), __builtin_bit_cast(unsigned long long, sums[i]),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
+  if (i < n) slots[blockIdx.y][i] = sums[i];
+  __syncthreads();
+  if (threadIdx.x == 0) __threadfence_system();
 }
 
 // step 2 (a later kernel of the same stream, so the stores above have been issued and fenced): raise my flag

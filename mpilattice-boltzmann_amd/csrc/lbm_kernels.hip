@@ -100,6 +100,7 @@ struct lbm_ctx {
   int accel_row = -1;
   int ghost = 0;             // storage rows below / above the owned rows (K-step kernels of a row-partitioned run)
   bool nt_stores = false;
+  bool fast_avvels = false;  // LBM_FLAG_FAST_AVVELS: float sum|u| terms in lbm_multi_kernel
   size_t ncells = 0, ncells_storage = 0, ps = 0, grid_floats = 0;   // owned cells; cells incl. ghost rows; plane stride
   float* grid_alloc[2] = {nullptr, nullptr};
   float* grid[2] = {nullptr, nullptr};       // plane 0 row 0 (after the front guard)
@@ -225,9 +226,10 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 }
 
 template <int K>
-void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a)
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, bool fast)
 {
-  lbm_multi_kernel<K><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K>::lds_bytes, s>>>(a);
+  if (fast) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K>::lds_bytes, s>>>(a);
+  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K>::lds_bytes, s>>>(a);
 }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
@@ -254,10 +256,10 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
   switch (std::min(ksteps, c->multi_K)) {
-    case 1: launch_multi_k<1>(blocks, s, a); break;
-    case 2: launch_multi_k<2>(blocks, s, a); break;
-    case 3: launch_multi_k<3>(blocks, s, a); break;
-    default: launch_multi_k<4>(blocks, s, a); break;
+    case 1: launch_multi_k<1>(blocks, s, a, c->fast_avvels); break;
+    case 2: launch_multi_k<2>(blocks, s, a, c->fast_avvels); break;
+    case 3: launch_multi_k<3>(blocks, s, a, c->fast_avvels); break;
+    default: launch_multi_k<4>(blocks, s, a, c->fast_avvels); break;
   }
 }
 
@@ -431,6 +433,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->free_cells_inv = 1.0f / free_cells;                                    // d2q9-bgk.c:950
   c->y0 = y0; c->nyl = ny_local; c->device = device; c->flags = flags;
   c->self_periodic = self_periodic;
+  c->fast_avvels = (flags & LBM_FLAG_FAST_AVVELS) != 0;
   c->accel_row = accel_row;
   c->accel_w1 = p->density * p->accel * 0.111111111111111111111111f;        // d2q9-bgk.c:445
   c->accel_w2 = p->density * p->accel * 0.0277777777777777777777778f;       // d2q9-bgk.c:446
@@ -1100,7 +1103,7 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, "lbm_multi_kernel<%d>", c->multi_K);
+    if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_multi_kernel<%d, fast av_vels>" : "lbm_multi_kernel<%d>", c->multi_K);
     else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");

@@ -110,7 +110,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
   a.epoch = epoch;
   a.parity = static_cast<unsigned long long>(g);
   a.done = t->done;
-  const dim3 grid((a.nfloats / 2 + 255) / 256, 9, 2);
+  const int work = 18 * (a.nfloats / 2);
+  const dim3 grid(std::max(1, std::min(kP2PPushBlocks, (work + 255) / 256)));
   hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -363,6 +364,8 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       c->n_prev = 0;
     }
     HIP_TRY(hipGetLastError());
+    // the next interior launch needs this macro-step's edge ROWS, not the push that follows them
+    if (t->edge_stream) HIP_TRY(hipEventRecord(t->edge_done, es));
     // state flip of lbm_macro_finish (d2q9-bgk.c:376-378)
     c->n_prev = c->multi_tiles;
     c->n_prev_vecs = k;
@@ -374,7 +377,6 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     if (more) {
       if (p2p_push(t, epoch + 1, es)) return 1;                // MPI_Startall (:327) for the next macro-step
     }
-    if (t->edge_stream) HIP_TRY(hipEventRecord(t->edge_done, es));
   }
   t->epoch = epoch - 1;
   if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));

@@ -37,15 +37,17 @@ free_cells = int(obst.size - obst.sum())
 cp = _capi.CParams(p.nx, p.ny, p.max_iters, p.reynolds_dim, p.density, p.accel, p.omega)
 
 ctxs = []
-for path in a.libs:
+for spec in a.libs:                       # "path.so" or "path.so:FLAGS" (lbm_create flags for that entry, e.g. 64 = fast av_vels)
+    path, _, fl = spec.partition(":")
+    flags = int(fl) if fl else a.flags
     lib = C.CDLL(os.path.abspath(path))
     for name in ("lbm_create", "lbm_run", "lbm_last_run_kernel_ms", "lbm_destroy", "lbm_last_error"):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = _capi._SIGNATURES[name]
     ctx = C.c_void_p()
-    if lib.lbm_create(C.byref(ctx), C.byref(cp), free_cells, obst.ctypes.data_as(C.POINTER(C.c_int)), 0, ny, 0, a.flags):
+    if lib.lbm_create(C.byref(ctx), C.byref(cp), free_cells, obst.ctypes.data_as(C.POINTER(C.c_int)), 0, ny, 0, flags):
         raise SystemExit(f"{path}: {lib.lbm_last_error().decode()}")
-    ctxs.append((path, lib, ctx))
+    ctxs.append((spec, lib, ctx))
 
 av = (C.c_float * a.steps)()
 res = {path: [] for path, _, _ in ctxs}
