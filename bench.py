@@ -441,12 +441,18 @@ def main() -> int:
             # GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): a ratio of cycles, so it does not depend on the clock the chip
             # holds (profiled passes run ~8 % slower than this un-profiled run, at a lower clock)
             frac_valu = pmc["frac_valu_profiled"]
-            roof.update({"traffic": pmc["hbm_bytes_per_launch"], "frac_hbm_physical": frac_hbm, "frac_valu": frac_valu,
-                         "bound": "hbm" if frac_hbm >= frac_valu else "valu", "achieved": hbm_gbs, "frac": max(frac_hbm, frac_valu),
-                         "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"), "pmc_source": pmc.get("source"),
-                         "note": "achieved/traffic = physical HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate "
-                                 "passes) over this run's launch time; frac_valu = 4 x SQ_ACTIVE_INST_VALU busy cycles per launch over "
-                                 "the cycles of the same profiled pass x 1024 SIMDs (a cycle ratio); frac = the larger (the binding limit)"})
+            simds = pmc.get("simds", 1024)
+            limits = {"hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm},
+                      "valu": {"achieved": frac_valu * simds, "peak": float(simds), "unit": "busy SIMDs", "frac": frac_valu}}
+            bound = "hbm" if frac_hbm >= frac_valu else "valu"
+            roof.update(limits[bound])
+            roof.update({"bound": bound, "traffic": pmc["hbm_bytes_per_launch"], "frac_hbm_physical": frac_hbm, "frac_valu": frac_valu,
+                         "limits": limits, "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
+                         "pmc_source": "profiles/r02/roofline.json (scripts/make_roofline.py over the rocprofv3 --pmc CSVs beside it)",
+                         "note": "two limits, each a fraction of something the chip can deliver; achieved/peak/frac are those of the larger "
+                                 "(`bound`).  hbm: physical bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) over THIS "
+                                 "run's launch time, against 8 TB/s.  valu: 4 x SQ_ACTIVE_INST_VALU busy cycles per launch over the cycles of the "
+                                 "same profiled pass (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs — a cycle ratio, independent of the clock held"})
         else:
             roof.update({"achieved": algo_gbs, "frac": None,
                          "note": "no PMC summary for this kernel/workload in profiles/r02/roofline.json: only the 108-B convention figure"})

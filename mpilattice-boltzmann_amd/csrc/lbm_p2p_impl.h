@@ -164,7 +164,6 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
       return fail();                                                                         \
     }                                                                                        \
   } while (0)
-  P2P_TRY(hipStreamCreateWithFlags(&t->edge, hipStreamNonBlocking));
   P2P_TRY(hipEventCreateWithFlags(&t->edge_done, hipEventDisableTiming));
   P2P_TRY(hipEventCreateWithFlags(&t->interior_done, hipEventDisableTiming));
   // exported window: flags + reduce slots.  Uncached device memory, so that a flag raised by a peer is seen
@@ -293,6 +292,9 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
     }
     p.mapped = true;
   }
+  // the edge stream exists only where the schedule uses it: every stream takes a share of the process's few
+  // hardware queues, and ranks of one process on one device must not share a queue (see above)
+  if (t->edge_stream && !t->edge) HIP_TRY(hipStreamCreateWithFlags(&t->edge, hipStreamNonBlocking));
   // device tables for the reduce kernels: where my sums go in every rank's window, and my flag there
   std::vector<double*> slots(static_cast<size_t>(2) * t->nranks);
   std::vector<unsigned long long*> flags(t->nranks);
@@ -399,7 +401,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     HIP_TRY(hipMemcpyAsync(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipStreamSynchronize(cs));
   }
-  HIP_TRY(hipStreamSynchronize(es));
+  if (t->edge_stream) HIP_TRY(hipStreamSynchronize(es));
   if (*t->err != 0) {
     const int e = *t->err;
     const char* who = e >= 100 ? "a neighbour's grids are out of step with this rank's (different number of steps run ?)"

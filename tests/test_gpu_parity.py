@@ -951,6 +951,23 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     assert out["launch_attempts"][0]["returncode"] == 0
 
 
+@pytest.mark.parametrize("gpus,name", [(2, "256x256_t1000"), (3, "1024x1024_t200"), (4, "128x256_t2000")])
+def test_cli_drives_several_ranks_from_one_process(lbm, digests, tmp_path, gpus, name):
+    """LBM_GPUS=N: the C shim as a single-process multi-GPU host — N ranks of the reference's decomposition, one
+    host thread each, peer-to-peer halos.  Here all ranks sit on device 0 (LBM_DEVICES), the way a one-GPU box
+    allows; same stdout contract, byte-identical final_state.dat, same Reynolds line as one rank."""
+    ppath, opath = deck_paths(name, digests)
+    env = dict(os.environ, LBM_GPUS=str(gpus), LBM_DEVICES=",".join(["0"] * gpus), LBM_P2P_TIMEOUT_MS="20000")
+    r = subprocess.run([lbm.CLI_PATH, ppath, opath], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "==done==" and out[1] == digests[name]["reynolds_line"]
+    assert f"({gpus} GPUs, peer-to-peer halos)" in out[5]
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
+    assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+
+
 def test_observables_path_writes_the_reference_file(lbm, digests, tmp_path):
     """lbm_get_observables (4 floats per cell computed on the device) + lbm_write_final_state_obs /
     lbm_av_velocity_obs against the 9-population path: same bytes, same Reynolds line; also on a random state
