@@ -23,15 +23,18 @@ namespace {
 // `ghost` extra rows below and above the owned rows, filled by the neighbours before the launch.
 // ------------------------------------------------------------------------------------------------
 constexpr int kMTX = 64, kMTY = 16, kMLanes = 512, kMaxMultiSteps = 4;
+// Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:
+// twice the tiles, each with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
+constexpr int kMTXNarrow = 32;
 
 // Sub-step j of k (1-based) works on the owned tile grown by (k-j) rows and 2(k-j) columns on each
 // side: columns grow twice as fast so that every region starts on an even x and a lane can own an
 // x-PAIR of cells (8-byte accesses; the two cells' arithmetic is packed by the compiler into
 // v_pk_*_f32, which halves the instruction count - the one-cell form of this kernel was VALU-bound).
-template <int K>
+template <int K, int TX = kMTX>
 struct MultiGeom {
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
-  static constexpr int W = kMTX + 2 * EX, H = kMTY + 2 * EY;        // LDS frame
+  static constexpr int W = TX + 2 * EX, H = kMTY + 2 * EY;          // LDS frame
   static constexpr int cells = W * H;
   static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64) + (K >= 2 ? cells / 2 : 0);   // + a flag byte per x-pair
 };
@@ -65,10 +68,10 @@ struct MultiArgs {
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
-template <int K, bool FAST>   // FAST: float sum|u| terms (LBM_FLAG_FAST_AVVELS), see finish_pair
+template <int K, bool FAST, int TX>   // FAST: float sum|u| terms (LBM_FLAG_FAST_AVVELS), see finish_pair; TX: tile width
 __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(const MultiArgs a)
 {
-  using G = MultiGeom<K>;
+  using G = MultiGeom<K, TX>;
   constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
   }
   const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int x0 = tx * kMTX;
+  const int x0 = tx * TX;
   const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
   const int nx = a.nx;
   const int rows_storage = a.rows_owned + 2 * a.ghost;
@@ -132,11 +135,11 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
   // ---- sub-step 1: pull from the source grid; region = owned tile grown by (ksteps-1) rows / 2(ksteps-1) columns
   {
     const int ey = ksteps - 1, ex = 2 * ey;
-    const int wp = (kMTX + 2 * ex) / 2;                                 // pairs per region row
+    const int wp = (TX + 2 * ex) / 2;                                 // pairs per region row
     const int np = wp * (kMTY + 2 * ey);
     // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
     // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
-    const bool inner = x0 - EX >= 2 && x0 + kMTX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + kMTY + EY + 1 <= rows_storage &&
+    const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + kMTY + EY + 1 <= rows_storage &&
                        sy0 + kMTY <= a.ghost + a.rows_owned;
 #pragma unroll 1
     for (int i = tid; i < np; i += kMLanes) {
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       f2 out[9];
       // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
       // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
-      const bool owned = fx >= EX && fx < EX + kMTX && fy >= EY && fy < EY + kMTY &&
+      const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + kMTY &&
                          (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
     // barrier, then writes; what it overwrites (old rows up to its last row - 1) no later pass reads.
     auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
       const int ey = ksteps - j, ex = 2 * ey;
-      const int wp = (kMTX + 2 * ex) / 2;                                // pairs per region row
+      const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
       const int rows = kMTY + 2 * ey;
       const int rpp = kMLanes / wp;                                      // whole rows per pass
       const bool last = j == ksteps;

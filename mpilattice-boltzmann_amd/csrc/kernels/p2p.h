@@ -32,7 +32,35 @@ struct P2PPushArgs {
   unsigned long long* parity_word[2];
   unsigned long long epoch, parity;
   unsigned int* done;                    // block-done counter (my device memory), zero between launches
+  // then wait (block 0, one lane) until BOTH neighbours' rows of the same epoch have arrived here: the push of a
+  // macro-step and the wait before the next one are always adjacent in the stream, and one kernel boundary less
+  // per macro-step is what a 1024 x 128-row partition notices (20 % of its step)
+  const unsigned long long* wait_flags;  // my halo_flag[2], or null: push only
+  const unsigned long long* wait_parity; // my halo_parity[4]
+  long long timeout_ticks;
+  int* err;
 };
+
+__device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, const unsigned long long* parity_words, int nflags, unsigned long long epoch,
+                                               unsigned long long parity, long long timeout_ticks, int* err)
+{
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  const long long t0 = wall_clock64();
+  for (int f = 0; f < nflags; ++f) {
+    while (__hip_atomic_load(flags + f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(err, 1 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);                             // ~128 cycles between polls: the flag is a remote write away
+    }
+    if (parity_words && __hip_atomic_load(parity_words + 2 * f + (epoch & 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
+      __hip_atomic_store(err, 100 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+  __threadfence_system();
+}
 
 // My first K owned rows -> the south neighbour's top ghost rows, my last K owned rows -> the north
 // neighbour's bottom ghost rows (all 9 planes), then the two epoch flags, raised by the last block to
@@ -46,11 +74,26 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
 {
   const int per_plane = a.nfloats / 2;                         // float2's of one plane's K rows (nx even)
   const int total = per_plane * 18;
-  for (int w = blockIdx.x * 256 + threadIdx.x; w < total; w += gridDim.x * 256) {
-    const int seg = w / per_plane, i = w - seg * per_plane;
-    const int dir = seg / 9, plane = seg - dir * 9;
-    const f2 v = *reinterpret_cast<const f2*>(a.src + plane * a.ps + a.src_row[dir] * nx + static_cast<size_t>(i) * 2);
-    *reinterpret_cast<f2*>(a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * 2) = v;
+  // four independent loads in flight per lane, then their stores: the kernel is a chain of memory round trips
+  // (a 1024 x 4-row message is 295 KB: one pass), not a bandwidth problem
+  constexpr int kUnroll = 4;
+  for (int w0 = blockIdx.x * 256 + threadIdx.x; w0 < total; w0 += gridDim.x * 256 * kUnroll) {
+    f2 v[kUnroll];
+    float* q[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int w = w0 + u * gridDim.x * 256;
+      q[u] = nullptr;
+      if (w < total) {
+        const int seg = w / per_plane, i = w - seg * per_plane;
+        const int dir = seg / 9, plane = seg - dir * 9;
+        v[u] = *reinterpret_cast<const f2*>(a.src + plane * a.ps + a.src_row[dir] * nx + static_cast<size_t>(i) * 2);
+        q[u] = a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * 2;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)
+      if (q[u]) *reinterpret_cast<f2*>(q[u]) = v[u];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -64,6 +107,9 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
         __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+    // my own push does not depend on this wait, so a ring of ranks that all sit here cannot dead-lock: every
+    // rank's flags are raised by blocks that never wait
+    if (blockIdx.x == 0 && a.wait_flags) p2p_wait_flags(a.wait_flags, a.wait_parity, 2, a.epoch, a.parity, a.timeout_ticks, a.err);
   }
 }
 
@@ -75,23 +121,7 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
 __global__ void __launch_bounds__(64) lbm_p2p_wait_kernel(const unsigned long long* flags, const unsigned long long* parity_words, int nflags,
                                                            unsigned long long epoch, unsigned long long parity, long long timeout_ticks, int* err)
 {
-  if (threadIdx.x != 0) return;
-  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
-  const long long t0 = wall_clock64();
-  for (int f = 0; f < nflags; ++f) {
-    while (__hip_atomic_load(flags + f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      if (wall_clock64() - t0 > timeout_ticks) {
-        __hip_atomic_store(err, 1 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(32);
-    }
-    if (parity_words && __hip_atomic_load(parity_words + 2 * f + (epoch & 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
-      __hip_atomic_store(err, 100 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-  }
-  __threadfence_system();
+  if (threadIdx.x == 0) p2p_wait_flags(flags, parity_words, nflags, epoch, parity, timeout_ticks, err);
 }
 
 // End-of-run reduction, step 1: my per-step sums into slot `my_rank` of EVERY rank's window (mine included).

@@ -138,6 +138,7 @@ struct lbm_ctx {
   int n_prev_vecs = 1;       // ... and how many step vectors of that length the previous launch left (tile kernel: up to 8)
   int multi_K = 0;           // > 0: bandwidth-bound grid advanced K steps per launch by lbm_multi_kernel<K>
   int multi_tiles_x = 0, multi_tiles = 0;
+  int multi_tx = kMTX;       // tile width of lbm_multi_kernel: 64, or 32 for partitions of one round of blocks
   bool tile_kernel = false;  // lbm_run advances several steps per launch with lbm_tile_kernel (small grids)
   int tile_T = 16, tile_H = 8;   // its geometry: owned tile edge, ghost ring = max steps per launch
   int n_tiles = 0;
@@ -225,11 +226,18 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
   }
 }
 
-template <int K>
-void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, bool fast)
+template <int K, int TX>
+void launch_multi_kt(int blocks, hipStream_t s, const MultiArgs& a, bool fast)
 {
-  if (fast) lbm_multi_kernel<K, true><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K>::lds_bytes, s>>>(a);
-  else lbm_multi_kernel<K, false><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K>::lds_bytes, s>>>(a);
+  if (fast) lbm_multi_kernel<K, true, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
+  else lbm_multi_kernel<K, false, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
+}
+
+template <int K>
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, bool fast, int tile_x)
+{
+  if (tile_x == kMTXNarrow) launch_multi_kt<K, kMTXNarrow>(blocks, s, a, fast);
+  else launch_multi_kt<K, kMTX>(blocks, s, a, fast);
 }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
@@ -256,10 +264,10 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
   switch (std::min(ksteps, c->multi_K)) {
-    case 1: launch_multi_k<1>(blocks, s, a, c->fast_avvels); break;
-    case 2: launch_multi_k<2>(blocks, s, a, c->fast_avvels); break;
-    case 3: launch_multi_k<3>(blocks, s, a, c->fast_avvels); break;
-    default: launch_multi_k<4>(blocks, s, a, c->fast_avvels); break;
+    case 1: launch_multi_k<1>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
+    case 2: launch_multi_k<2>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
+    case 3: launch_multi_k<3>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
+    default: launch_multi_k<4>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
   }
 }
 
@@ -368,6 +376,18 @@ static int macro_k_for(size_t max_cells)
 {
   const int by_size = max_cells < (1u << 21) ? 4 : 3;
   return std::min(std::max(tune_env("LBM_TUNE_MACRO_K", by_size), 0), kMaxMultiSteps);
+}
+
+// Tile width of lbm_multi_kernel by partition size: 64 x 16 tiles for the bandwidth-bound grids; 32 x 16 where 64 x 16
+// tiles would not even fill the chip once (256 CUs x 3 blocks), so that the launch is bound by one block's chain of
+// sub-steps: half the work per block, twice the blocks.  Measured us/step for 64 / 32 wide tiles (K = 3, one GPU):
+// 1024x128 3.22 / 2.53, 512x256 3.17 / 2.50, 512x512 3.42 / 3.44, 2048x256 4.94 / 5.05, 1024x1024 8.39 / 9.01.
+// LBM_TUNE_MULTI_TILE = 64 / 32 overrides.
+static int pick_tile_x(size_t ncells)
+{
+  const int by_size = ncells <= static_cast<size_t>(tune_env("LBM_TUNE_NARROW_TILE_MAX", 1 << 17)) ? kMTXNarrow : kMTX;
+  const int t = tune_env("LBM_TUNE_MULTI_TILE", by_size);
+  return t == kMTXNarrow ? kMTXNarrow : kMTX;
 }
 
 // Obstacle bitfield of the storage rows: bit i of the linear storage cell index, row r of the storage taken
@@ -539,7 +559,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
-    c->multi_tiles_x = (p->nx + kMTX - 1) / kMTX;
+    c->multi_tx = pick_tile_x(c->ncells);
+    c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
   } else if (!c->tile_kernel && self_periodic && fits_u32 &&
@@ -551,7 +572,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     //   1024x1024 11.2 / 8.3 / 8.5 (13.5)   512x512 3.7 / 3.4 / 3.3 (6.3; lbm_tile_kernel 5.2)
     // K = 2 is HBM-bound, K = 4 instruction-bound at 2 blocks per CU (60 KB frames); K = 3 sits at both limits
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 3), 0), kMaxMultiSteps);
-    c->multi_tiles_x = (p->nx + kMTX - 1) / kMTX;
+    c->multi_tx = pick_tile_x(c->ncells);
+    c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
   } else if (c->tile_kernel) {

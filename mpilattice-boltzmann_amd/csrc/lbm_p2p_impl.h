@@ -6,15 +6,18 @@
 //
 //   compute stream                    edge stream
 //   ──────────────                    ───────────
-//   wait(edge rows m-1)               wait kernel: both neighbours' flags >= epoch(m)   MPI_Waitall (:364)
-//   interior tiles m      (:350)      wait(interior m-1)
-//   record(interior m)                edge tile rows m                        (:365-366)
-//                                     push kernel: my edge rows of the NEW state -> neighbours' ghost rows,
-//                                                  flags := epoch(m+1)                  MPI_Startall (:327)
+//   wait(edge rows m-1)               push kernel: my edge rows of the current state -> neighbours' ghost rows,
+//   interior tiles m      (:350)                   flags := epoch(m)                    MPI_Startall (:327)
+//   record(interior m)                             then wait: both neighbours' flags >= epoch(m)   MPI_Waitall (:364)
+//                                     wait(interior m-1)
+//                                     edge tile rows m                        (:365-366)
 //                                     record(edge rows m)
 //
-// Small partitions (< 2 M cells) run everything on the compute stream with ONE launch over all tiles:
-// there the two cross-queue waits cost more than the overlap hides (measured for the RCCL loop).
+// Small partitions (< 2 M cells) run everything on the compute stream, two kernels per macro-step — ONE launch
+// over all tiles, then the push + wait kernel: there the two cross-queue waits cost more than the overlap hides.
+// (Tried and dropped: the push fused into the step launch, the edge tiles storing their rows to the neighbours
+// as well and the last of them raising the flags and waiting — 5.9 instead of 4.3 us/step on a 1024 x 128-row
+// ring: every pushing tile's system-scope fence writes back an L2 that the whole launch is streaming through.)
 #pragma once
 
 #include <unistd.h>
@@ -85,7 +88,7 @@ void p2p_unmap(lbm_p2p* t)
 }
 
 // The K rows of the CURRENT grid that the neighbours need, into their ghost rows of the grid with the same
-// parity, flags := epoch.
+// parity, flags := epoch; then (same kernel) wait for the neighbours' rows of that epoch to have arrived here.
 int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
 {
   lbm_ctx* c = t->ctx;
@@ -110,18 +113,15 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
   a.epoch = epoch;
   a.parity = static_cast<unsigned long long>(g);
   a.done = t->done;
+  a.wait_flags = header_of(t->window)->halo_flag;
+  a.wait_parity = header_of(t->window)->halo_parity;
+  a.timeout_ticks = t->timeout_ticks;
+  a.err = t->err;
   const int work = 18 * (a.nfloats / 2);
-  const dim3 grid(std::max(1, std::min(kP2PPushBlocks, (work + 255) / 256)));
+  // at most 64 blocks (every block ends with an L2 write-back towards the peers), each lane moving up to four
+  // float2's per pass
+  const dim3 grid(std::max(1, std::min(kP2PPushBlocks, (work + 1023) / 1024)));
   hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int p2p_wait_halos(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
-{
-  P2PWindowHeader* h = header_of(t->window);
-  hipLaunchKernelGGL(lbm_p2p_wait_kernel, dim3(1), dim3(64), 0, s, h->halo_flag, h->halo_parity, 2, epoch,
-                     static_cast<unsigned long long>(t->ctx->cur), t->timeout_ticks, t->err);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -354,14 +354,13 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
         launch_multi(c, k, more, c->multi_tiles_x, c->multi_tiles_x * rows.interior_rows, 0, 0, /*fold=*/c->n_prev > 0, cs);
         c->n_prev = 0;
       }
-      if (p2p_wait_halos(t, epoch, es)) return 1;              // MPI_Waitall (:364), on the device
+      // MPI_Waitall (:364) happened on the device, at the end of the push kernel that precedes this launch
       HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
       launch_multi(c, k, more, 0, c->multi_tiles_x, (1 + rows.interior_rows) * c->multi_tiles_x, rows.top_edge_rows * c->multi_tiles_x,
                    /*fold=*/c->n_prev > 0, es);               // :365-366
       c->n_prev = 0;
       HIP_TRY(hipEventRecord(t->interior_done, cs));
     } else {
-      if (p2p_wait_halos(t, epoch, cs)) return 1;
       launch_multi(c, k, more, 0, c->multi_tiles, 0, 0, /*fold=*/c->n_prev > 0, cs);
       c->n_prev = 0;
     }

@@ -564,11 +564,14 @@ STRESS = ["open", "dense", "accel_row_blocked", "strong_accel", "omega_low", "om
 
 
 @pytest.mark.parametrize("K", [2, 3, 4])
+@pytest.mark.parametrize("tile", [64, 32])
 @pytest.mark.parametrize("kind", STRESS)
-def test_multi_kernel_rare_paths(lbm, oracle, monkeypatch, kind, K):
+def test_multi_kernel_rare_paths(lbm, oracle, monkeypatch, kind, K, tile):
     """Whole periodic grid (edge tiles only at 256x64, inner tiles too at 448x112) through
-    lbm_multi_kernel<K>: uniform branches for accelerate_flow / bounce-back / inner tiles, pair flags."""
+    lbm_multi_kernel<K>: uniform branches for accelerate_flow / bounce-back / inner tiles, pair flags;
+    both tile widths (64 x 16, and the 32 x 16 form small partitions get)."""
     monkeypatch.setenv("LBM_TUNE_MULTI_K", str(K))
+    monkeypatch.setenv("LBM_TUNE_MULTI_TILE", str(tile))
     monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
     for nx, ny in ((256, 64), (448, 112)):
         p, obst = _stress_deck(lbm, kind, nx, ny)
@@ -582,11 +585,13 @@ def test_multi_kernel_rare_paths(lbm, oracle, monkeypatch, kind, K):
         assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL
 
 
+@pytest.mark.parametrize("tile", [64, 32])
 @pytest.mark.parametrize("kind", STRESS)
-def test_k_step_partitions_rare_paths(lbm, oracle, monkeypatch, kind):
+def test_k_step_partitions_rare_paths(lbm, oracle, monkeypatch, kind, tile):
     """The same decks as K-step row partitions exchanged in-process (3 partitions of 448x112: the
     accelerate row lies in one partition's owned rows and in its neighbour's ghost rows)."""
     monkeypatch.setenv("LBM_TUNE_MACRO_K", "3")
+    monkeypatch.setenv("LBM_TUNE_MULTI_TILE", str(tile))
     p, obst = _stress_deck(lbm, kind, 448, 112)
     ny_local, displs = lbm.decompose(p.ny, 3)
     free = int(obst.size - obst.sum())
@@ -641,11 +646,13 @@ def test_k_step_mode_with_several_partitions(lbm, oracle, digests, monkeypatch, 
 
 
 @pytest.mark.parametrize("K", [2, 3, 4])
-@pytest.mark.parametrize("nx,ny", [(128, 32), (130, 34), (200, 150), (1000, 1000), (1026, 258), (190, 47)])
-def test_k_steps_kernel_on_grids_that_tiles_do_not_divide(lbm, oracle, monkeypatch, nx, ny, K):
+@pytest.mark.parametrize("nx,ny,tile", [(128, 32, 64), (130, 34, 64), (200, 150, 64), (1000, 1000, 64), (1026, 258, 64), (190, 47, 64),
+                                        (130, 34, 32), (200, 150, 32), (1000, 1000, 32), (190, 47, 32)])
+def test_k_steps_kernel_on_grids_that_tiles_do_not_divide(lbm, oracle, monkeypatch, nx, ny, K, tile):
     """Even nx >= 128, ny >= 32: the last tile column / row of lbm_multi_kernel sticks out of the grid;
     the overhanging cells are periodic images that are computed but neither stored nor summed."""
     monkeypatch.setenv("LBM_TUNE_MULTI_K", str(K))
+    monkeypatch.setenv("LBM_TUNE_MULTI_TILE", str(tile))
     monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
     steps = 40 if nx * ny > 500000 else 95
     p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
