@@ -1054,3 +1054,43 @@ def test_rank_partitions_from_windows_only(lbm, oracle, monkeypatch):
     assert np.array_equal(bits(cells), bits(ref_cells))
     av = sums * np.float64(np.float32(1.0) / np.float32(free))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["128x128", "128x256", "256x256", "1024x1024"])
+def test_fast_av_vels_flag_on_the_shipped_decks(lbm, digests, tmp_path, monkeypatch, name):
+    """LBM_FLAG_FAST_AVVELS (float sum|u| terms in lbm_multi_kernel, default off): populations must not move by a
+    bit (final_state.dat still the reference binary's file) and av_vels must stay inside check.py's 1 % against the
+    shipped (double-precision) goldens on all four decks — observed: as close as the exact-term form."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")                     # the small decks through lbm_multi_kernel too
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FAST_AVVELS)
+    assert sim.partition.describe()["kernel"] == "lbm_multi_kernel<3, fast av_vels>"
+    av = sim.run()
+    sim.write_values(av, str(tmp_path))
+    sim.close()
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    ck = lbm.checker
+    rep = ck.check_files(os.path.join(GOLDEN, "check", f"{name}.av_vels.dat.gz"), None, str(tmp_path / "av_vels.dat"), None)
+    assert rep.ok and abs(rep.av_vels.max_diff_pcnt) < 0.3, rep.message
+    steps = np.asarray(digests[name]["av_sample_steps"])
+    assert np.allclose(av[steps], digests[name]["av_sample_values"], rtol=4e-3 if name == "1024x1024" else 5e-4)
+
+
+@pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 100), ("1024x1024_t200", 200), ("rand_64x48", 103)])
+def test_fast_av_vels_flag_against_the_oracle(lbm, oracle, digests, monkeypatch, name, steps):
+    """The same flag against the oracle's exact per-step sums: 1e-6 relative (observed ~1e-8), state bit-exact."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    p, obst, free = load_case(lbm, digests, name)
+    if p.nx % 64 or p.ny % 16:
+        pytest.skip("not a multi-kernel grid")
+    exact = lbm.Simulation(p, obst)
+    fast = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FAST_AVVELS)
+    av_e, av_f = exact.run(steps), fast.run(steps)
+    assert np.array_equal(bits(exact.local_cells()), bits(fast.local_cells()))
+    exact.close()
+    cells = fast.local_cells()
+    fast.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av_f - ref_exact) / ref_exact) < AV_EXACT_RTOL
+    assert np.max(np.abs(av_f.astype(np.float64) - av_e) / av_e) < 1e-6
