@@ -48,6 +48,7 @@ struct TileArgs {
   int nx, ny;
   int tiles_x;                 // nx / T
   int ksteps;                  // 1..H steps in this launch
+  int single_max;              // sub-steps whose region holds at most this many cells deal ONE cell per lane (0: always x-pairs)
   float omega, accel_w1, accel_w2;
   int accel_row;               // ny-2
   int accel_last;              // apply accelerate_flow after the LAST sub-step too (another step follows)
@@ -126,36 +127,70 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
     float* bufB = lds + ((S & 1) ? 9 * kCells : 0);
     // cells still needed after this sub-step: the owned tile expanded by e = k_total - S
     const int e = k_total - S;
-    const int w = T / 2 + e;                          // pairs per row of that region
-    if (tid < w * (T + 2 * e)) {
-      const int ry = small_div(tid, w), rp = tid - ry * w;
-      const int x = H - e + 2 * rp, y = H - e + ry;   // region cells (x, y), (x+1, y)
-      const int c = y * R + x;
-      const uint32_t fl0 = cell_flags[c], fl1 = cell_flags[c + 1];
-      const uint32_t mbits = (fl0 & 1u) | ((fl1 & 1u) << 1);
-      // a pair that starts on an odd x may straddle the edge of the owned tile: per-cell skip bits
-      const uint32_t skip = (((fl0 & 1u) | ((fl0 & 2u) ? 0u : 1u))) | (((fl1 & 1u) | ((fl1 & 2u) ? 0u : 1u)) << 1);
-      f2 p[9], out[9];                                                           // d2q9-bgk.c:530-538
-      p[0] = f2{bufA[0 * kCells + c], bufA[0 * kCells + c + 1]};
-      p[2] = f2{bufA[2 * kCells + c - R], bufA[2 * kCells + c - R + 1]};
-      p[4] = f2{bufA[4 * kCells + c + R], bufA[4 * kCells + c + R + 1]};
-      p[1] = f2{bufA[1 * kCells + c - 1], bufA[1 * kCells + c]};
-      p[5] = f2{bufA[5 * kCells + c - R - 1], bufA[5 * kCells + c - R]};
-      p[8] = f2{bufA[8 * kCells + c + R - 1], bufA[8 * kCells + c + R]};
-      p[3] = f2{bufA[3 * kCells + c + 1], bufA[3 * kCells + c + 2]};
-      p[6] = f2{bufA[6 * kCells + c - R + 1], bufA[6 * kCells + c - R + 2]};
-      p[7] = f2{bufA[7 * kCells + c + R + 1], bufA[7 * kCells + c + R + 2]};
-      // relaxation, bounce-back (:687-695), accelerate_flow of the following step (:457-469), sum|u| terms
-      acc[S - 1] = finish_pair(p, mbits, a.omega, tile_accel, (fl0 & 4u) && (S < k_total || a.accel_last), a.accel_w1, a.accel_w2,
-                               skip, out);
-      if (S < k_total) {
+    const int side = T + 2 * e;
+    if (side * side <= a.single_max && side * side <= kLanes) {   // block-uniform
+      // Late sub-steps: the region fits the block's SIMDs with one CELL per lane — a wave alone on its SIMD issues an
+      // instruction every 4+ cycles whether it is packed or not, so what counts is the length of one lane's chain:
+      // ~190 instructions for a cell against ~330 for an x-pair (division, double sqrt and the unaligned LDS
+      // accesses are per cell either way).  Same relax_core, same order of operations: the same bits.
+      if (tid < side * side) {
+        const int ry = small_div(tid, side), rx = tid - ry * side;
+        const int x = H - e + rx, y = H - e + ry;
+        const int c = y * R + x;
+        const uint32_t fl = cell_flags[c];
+        float t[9], o[9], out[9];                                                  // d2q9-bgk.c:530-538
+        t[0] = bufA[0 * kCells + c];         t[1] = bufA[1 * kCells + c - 1];     t[2] = bufA[2 * kCells + c - R];
+        t[3] = bufA[3 * kCells + c + 1];     t[4] = bufA[4 * kCells + c + R];     t[5] = bufA[5 * kCells + c - R - 1];
+        t[6] = bufA[6 * kCells + c - R + 1]; t[7] = bufA[7 * kCells + c + R + 1]; t[8] = bufA[8 * kCells + c + R - 1];
+        float msq, rinv;
+        relax_core<float>(t, a.omega, o, msq, rinv);
+        const bool blocked = fl & 1u;
+        bounce_or_relax(t, o, blocked, out);                                      // :687-695
+        if (tile_accel && (fl & 4u) && !blocked && (S < k_total || a.accel_last)) accelerate_cell(out, a.accel_w1, a.accel_w2);   // :457-469
+        double term = 0.0;
+        if ((fl & 3u) == 2u) term = sqrt_of_float(msq) * static_cast<double>(rinv);   // owned fluid cell (:667)
+        acc[S - 1] = term;
+        if (S < k_total) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { bufB[k * kCells + c] = out[k].x; bufB[k * kCells + c + 1] = out[k].y; }
-      } else {
-        // last sub-step: the region is the owned tile (x = H + 2 rp, y = H + ry), inside the grid
-        const int cell = (ty * T + ry) * a.nx + tx * T + 2 * rp;
+          for (int k = 0; k < 9; ++k) bufB[k * kCells + c] = out[k];
+        } else {
+          const int cell = (ty * T + ry) * a.nx + tx * T + rx;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(a.dst + k * a.ps + cell) = out[k];
+          for (int k = 0; k < 9; ++k) a.dst[k * a.ps + cell] = out[k];
+        }
+      }
+    } else {
+      const int w = T / 2 + e;                          // pairs per row of that region
+      if (tid < w * (T + 2 * e)) {
+        const int ry = small_div(tid, w), rp = tid - ry * w;
+        const int x = H - e + 2 * rp, y = H - e + ry;   // region cells (x, y), (x+1, y)
+        const int c = y * R + x;
+        const uint32_t fl0 = cell_flags[c], fl1 = cell_flags[c + 1];
+        const uint32_t mbits = (fl0 & 1u) | ((fl1 & 1u) << 1);
+        // a pair that starts on an odd x may straddle the edge of the owned tile: per-cell skip bits
+        const uint32_t skip = (((fl0 & 1u) | ((fl0 & 2u) ? 0u : 1u))) | (((fl1 & 1u) | ((fl1 & 2u) ? 0u : 1u)) << 1);
+        f2 p[9], out[9];                                                           // d2q9-bgk.c:530-538
+        p[0] = f2{bufA[0 * kCells + c], bufA[0 * kCells + c + 1]};
+        p[2] = f2{bufA[2 * kCells + c - R], bufA[2 * kCells + c - R + 1]};
+        p[4] = f2{bufA[4 * kCells + c + R], bufA[4 * kCells + c + R + 1]};
+        p[1] = f2{bufA[1 * kCells + c - 1], bufA[1 * kCells + c]};
+        p[5] = f2{bufA[5 * kCells + c - R - 1], bufA[5 * kCells + c - R]};
+        p[8] = f2{bufA[8 * kCells + c + R - 1], bufA[8 * kCells + c + R]};
+        p[3] = f2{bufA[3 * kCells + c + 1], bufA[3 * kCells + c + 2]};
+        p[6] = f2{bufA[6 * kCells + c - R + 1], bufA[6 * kCells + c - R + 2]};
+        p[7] = f2{bufA[7 * kCells + c + R + 1], bufA[7 * kCells + c + R + 2]};
+        // relaxation, bounce-back (:687-695), accelerate_flow of the following step (:457-469), sum|u| terms
+        acc[S - 1] = finish_pair(p, mbits, a.omega, tile_accel, (fl0 & 4u) && (S < k_total || a.accel_last), a.accel_w1, a.accel_w2,
+                                 skip, out);
+        if (S < k_total) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { bufB[k * kCells + c] = out[k].x; bufB[k * kCells + c + 1] = out[k].y; }
+        } else {
+          // last sub-step: the region is the owned tile (x = H + 2 rp, y = H + ry), inside the grid
+          const int cell = (ty * T + ry) * a.nx + tx * T + 2 * rp;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(a.dst + k * a.ps + cell) = out[k];
+        }
       }
     }
     if (S < k_total) __syncthreads();

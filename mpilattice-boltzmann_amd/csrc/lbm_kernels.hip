@@ -141,6 +141,7 @@ struct lbm_ctx {
   int multi_tx = kMTX;       // tile width of lbm_multi_kernel: 64, or 32 for partitions of one round of blocks
   bool tile_kernel = false;  // lbm_run advances several steps per launch with lbm_tile_kernel (small grids)
   int tile_T = 16, tile_H = 8;   // its geometry: owned tile edge, ghost ring = max steps per launch
+  int tile_single_max = 0;       // sub-steps with regions of at most this many cells deal one cell per lane
   int n_tiles = 0;
   float accel_w1 = 0.f, accel_w2 = 0.f;
 };
@@ -552,6 +553,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->tile_T = geom / 10; c->tile_H = geom % 10;
     if (!((c->tile_T == 16 || c->tile_T == 8) && (c->tile_H == 8 || c->tile_H == 4))) { c->tile_T = 16; c->tile_H = 4; }
   }
+  // measured whole-deck times (s) for 0 / 256 / 512: 128x128 0.0648 / 0.0576 / 0.0565, 128x256 0.0746 / 0.0747 / 0.0712,
+  // 256x256 0.1598 / 0.1570 / 0.1532
+  c->tile_single_max = tune_env("LBM_TUNE_TILE_SINGLE_MAX", 512);
   c->n_tiles = (p->nx % c->tile_T == 0 && ny_local % c->tile_T == 0) ? (p->nx / c->tile_T) * (ny_local / c->tile_T) : 0;
   c->tile_kernel = self_periodic && c->n_tiles > 0 &&
                    c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 131072));  // us/step here vs lbm_multi_kernel<3>: 256x256 1.9 / 3.1, 512x256 2.8 / 3.2, 384x384 3.6 / 3.2, 512x512 4.5 / 3.3
@@ -700,6 +704,7 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
     a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx; a.ny = c->nyl; a.tiles_x = c->p.nx / c->tile_T;
     a.ksteps = k;
+    a.single_max = c->tile_single_max;
     a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
     a.accel_row = c->accel_row; a.accel_last = (t + k < n_steps) ? 1 : 0;
     a.partials_out = c->partials[c->parity];

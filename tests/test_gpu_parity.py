@@ -873,35 +873,18 @@ def test_p2p_ranks_in_separate_processes_share_the_gpu(lbm, ranks):
 
 
 @pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge")])
-def test_p2p_partitions_in_one_process(lbm, oracle, monkeypatch, nx, ny, size, K, schedule):
+def test_p2p_partitions_in_one_process(lbm, nx, ny, size, K, schedule):
     """Several ranks of one run as contexts of ONE process (one host thread per rank, as a single-process
-    multi-GPU host drives them), connected through plain pointers instead of IPC handles.  Ranks of one
-    process that share a DEVICE run the serial schedule whatever was asked for: their streams share the
-    process's few hardware queues, and a wait kernel must never sit in front of the push it waits for."""
-    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
-    monkeypatch.setenv("LBM_P2P_SCHEDULE", schedule)
-    monkeypatch.setenv("LBM_P2P_TIMEOUT_MS", "10000")
-    steps = 31
-    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
-    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 5 + ny, False)
-    free = lbm.count_free_cells(obst)
-    lays = [lbm.rank_layout(p, size, r) for r in range(size)]
-    assert all(l["macro_k"] == K for l in lays), lays
-    parts = [lbm.Partition(p, free, lbm.obstacle_window(obst, lays[r]), rank_of=(r, size)) for r in range(size)]
-    rings = lbm.P2PRing.local_ring(parts)
-    a = lbm.P2PRing.run_all(rings, 20)
-    b = lbm.P2PRing.run_all(rings, 11)
-    for r in range(1, size):                                    # the reduction is bitwise the same on every rank
-        assert np.array_equal(a[r], a[0]) and np.array_equal(b[r], b[0])
-    cells = np.concatenate([q.get_cells() for q in parts], axis=0)
-    for ring in rings:
-        ring.close()
-    for q in parts:
-        q.close()
-    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
-    assert np.array_equal(bits(cells), bits(ref_cells))
-    av = np.concatenate([a[0], b[0]]) * np.float64(np.float32(1.0) / np.float32(free))
-    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+    multi-GPU host drives them), connected through plain pointers instead of IPC handles
+    (tests/p2p_inprocess_worker.py).  Ranks of one process that share a DEVICE run the serial schedule whatever
+    was asked for and need a hardware queue each (a wait kernel must never sit in front of the push it waits
+    for), hence the fresh process with GPU_MAX_HW_QUEUES raised, as the C shim does for LBM_GPUS."""
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", LBM_P2P_TIMEOUT_MS="10000")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "p2p_inprocess_worker.py"), str(nx), str(ny), str(size), str(K), schedule],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "IN-PROCESS RING ok" in r.stdout, r.stderr[-3000:]
 
 
 def test_p2p_refuses_ranks_with_different_layouts(lbm, monkeypatch):
