@@ -57,6 +57,7 @@ def parse_args(argv=None):
                          "ops; auto = try them in that order")
     ap.add_argument("--step-allreduce", action="store_true",
                     help="RCCL loop: one all-reduce per (macro-)step instead of one after the loop (north_star wording; measured mode)")
+    ap.add_argument("--no-variants", action="store_true", help="N=1: skip the extra timing of the same deck with LBM_FLAG_FAST_AVVELS")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-exact check against a single-GPU run of the same deck")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the 1-core port sample")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="self-launch: seconds before a set of rank processes is given up")
@@ -396,6 +397,26 @@ def main() -> int:
     what = sim.describe()
     steps_done = args.warmup + args.steps * max(1, args.reps)
 
+    # N = 1: the same deck with LBM_FLAG_FAST_AVVELS (float sum|u| terms; default off) — both figures side by side
+    variants = None
+    if world == 1 and not args.ring and not args.no_variants:
+        alt = lbm.Simulation(params, obstacles, device=local_rank, flags=flags | lbm._capi.FLAG_FAST_AVVELS)
+        if "fast av_vels" in alt.partition.describe()["kernel"]:
+            alt.run(args.warmup)
+            talt, av_alt = [], None
+            for _ in range(max(1, args.reps)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                av_alt = alt.run(args.steps)
+                torch.cuda.synchronize()
+                talt.append(time.perf_counter() - t0)
+            med = float(np.median(talt))
+            variants = {"fast_av_vels": {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
+                                         "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt.astype(np.float64) - av) / av)),
+                                         "note": "LBM_FLAG_FAST_AVVELS: each cell's sum|u| term in float instead of double; populations "
+                                                 "identical bit for bit; NOT the headline (default off)"}}
+        alt.close()
+
     verify = None
     if verify_on:
         good, same, av_err = check_against_single_gpu(sim, av, steps_done)
@@ -478,6 +499,8 @@ def main() -> int:
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": roof,
         }
+        if variants is not None:
+            out["variants"] = variants
         if verify is not None:
             out["parity_check"] = verify
         if partitioned:

@@ -59,7 +59,7 @@ struct TileArgs {
   int* counter;
 };
 
-template <int T, int H, bool FULL>   // FULL: this launch does exactly H steps (region sizes are compile-time constants)
+template <int T, int H, bool FULL, bool FAST>   // FULL: this launch does exactly H steps (region sizes are compile-time constants); FAST: float sum|u| terms
 __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel(const TileArgs a)
 {
   using G = TileGeom<T, H>;
@@ -148,7 +148,8 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
         bounce_or_relax(t, o, blocked, out);                                      // :687-695
         if (tile_accel && (fl & 4u) && !blocked && (S < k_total || a.accel_last)) accelerate_cell(out, a.accel_w1, a.accel_w2);   // :457-469
         double term = 0.0;
-        if ((fl & 3u) == 2u) term = sqrt_of_float(msq) * static_cast<double>(rinv);   // owned fluid cell (:667)
+        if ((fl & 3u) == 2u)                                                          // owned fluid cell (:667)
+          term = FAST ? static_cast<double>(__builtin_amdgcn_sqrtf(msq) * rinv) : sqrt_of_float(msq) * static_cast<double>(rinv);
         acc[S - 1] = term;
         if (S < k_total) {
 #pragma unroll
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
         p[6] = f2{bufA[6 * kCells + c - R + 1], bufA[6 * kCells + c - R + 2]};
         p[7] = f2{bufA[7 * kCells + c + R + 1], bufA[7 * kCells + c + R + 2]};
         // relaxation, bounce-back (:687-695), accelerate_flow of the following step (:457-469), sum|u| terms
-        acc[S - 1] = finish_pair(p, mbits, a.omega, tile_accel, (fl0 & 4u) && (S < k_total || a.accel_last), a.accel_w1, a.accel_w2,
+        acc[S - 1] = finish_pair<FAST>(p, mbits, a.omega, tile_accel, (fl0 & 4u) && (S < k_total || a.accel_last), a.accel_w1, a.accel_w2,
                                  skip, out);
         if (S < k_total) {
 #pragma unroll

@@ -273,11 +273,16 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
 }
 
 template <int T, int H>
-void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a)
+void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a, bool fast)
 {
   using G = TileGeom<T, H>;
-  if (a.ksteps == H) lbm_tile_kernel<T, H, true><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
-  else lbm_tile_kernel<T, H, false><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+  if (fast) {
+    if (a.ksteps == H) lbm_tile_kernel<T, H, true, true><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+    else lbm_tile_kernel<T, H, false, true><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+  } else {
+    if (a.ksteps == H) lbm_tile_kernel<T, H, true, false><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+    else lbm_tile_kernel<T, H, false, false><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+  }
 }
 
 int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
@@ -585,12 +590,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // up to 74 KB of dynamic LDS per block (two 9 x R x R float buffers): above the 64 KB default limit
     {
       using G168 = TileGeom<16, 8>;
-      auto* k168 = &lbm_tile_kernel<16, 8, true>;
-      auto* k168t = &lbm_tile_kernel<16, 8, false>;
-      HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k168), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(G168::lds_bytes)));
-      HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k168t), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(G168::lds_bytes)));
+      const void* big[4] = {reinterpret_cast<const void*>(&lbm_tile_kernel<16, 8, true, false>), reinterpret_cast<const void*>(&lbm_tile_kernel<16, 8, false, false>),
+                            reinterpret_cast<const void*>(&lbm_tile_kernel<16, 8, true, true>), reinterpret_cast<const void*>(&lbm_tile_kernel<16, 8, false, true>)};
+      for (const void* k : big) HIP_TRY_C(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G168::lds_bytes)));
     }
   }
   for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->partials[i], sizeof(double) * c->partials_cap));
@@ -712,10 +714,10 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     a.n_prev = c->n_prev; a.n_prev_vecs = c->n_prev > 0 ? c->n_prev_vecs : 0;
     a.sums = c->sums; a.counter = c->counter;
     const dim3 grid(c->n_tiles + 1);
-    if (c->tile_T == 16 && c->tile_H == 8) launch_tile<16, 8>(grid, s, a);
-    else if (c->tile_T == 16) launch_tile<16, 4>(grid, s, a);
-    else if (c->tile_H == 8) launch_tile<8, 8>(grid, s, a);
-    else launch_tile<8, 4>(grid, s, a);
+    if (c->tile_T == 16 && c->tile_H == 8) launch_tile<16, 8>(grid, s, a, c->fast_avvels);
+    else if (c->tile_T == 16) launch_tile<16, 4>(grid, s, a, c->fast_avvels);
+    else if (c->tile_H == 8) launch_tile<8, 8>(grid, s, a, c->fast_avvels);
+    else launch_tile<8, 4>(grid, s, a, c->fast_avvels);
     ++tile_launches;
     c->n_prev = c->n_tiles; c->n_prev_vecs = k;
     c->parity ^= 1;
@@ -1131,7 +1133,7 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
     if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_multi_kernel<%d, fast av_vels>" : "lbm_multi_kernel<%d>", c->multi_K);
-    else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
+    else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_tile_kernel<%d, %d, fast av_vels>" : "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
     else std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");

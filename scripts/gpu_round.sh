@@ -12,13 +12,8 @@ if [ "$2" != "skip-tests" ]; then
   timeout -k 10 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_$TAG.log 2>&1 || (tail -40 $OUT/pytest_gpu_$TAG.log; exit 1)
   tail -5 $OUT/pytest_gpu_$TAG.log
 fi
-python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || (cat $OUT/bench_$TAG.err; exit 1)
-cat $OUT/bench_$TAG.json | cut -c1-400
-# the driver's own invocation: short timed region
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_style_$TAG.json 2>> $OUT/bench_$TAG.err
-cat $OUT/bench_driver_style_$TAG.json | cut -c1-200
 cd /tmp
-B="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --reps 1"
+B="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --reps 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $B --steps 100 --warmup 10 > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -o pmc -- python3 $B --steps 18 --warmup 3 > /dev/null 2> $OUT/pmc_${TAG}_fetch.err
@@ -29,6 +24,12 @@ rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 echo sq passes done
 cd $GRAFT_REPO_ROOT
 python scripts/make_roofline.py $TAG $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/pmc_${TAG}_sq1 $OUT/pmc_${TAG}_sq2 | tail -30
+# the bench lines AFTER the PMC passes of this session: roofline.* then comes from the counters of the same build on the same box
+python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || (cat $OUT/bench_$TAG.err; exit 1)
+cat $OUT/bench_$TAG.json | cut -c1-400
+# the driver's own invocation: short timed region
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_style_$TAG.json 2>> $OUT/bench_$TAG.err
+cat $OUT/bench_driver_style_$TAG.json | cut -c1-200
 mkdir -p $OUT/profiles_$TAG && cp -r profiles/$TAG/* $OUT/profiles_$TAG/
 find $OUT/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $OUT/profiles_$TAG/kernel_stats_bench_8192.csv \;
 cp $OUT/bench_$TAG.json $OUT/profiles_$TAG/bench_n1.json

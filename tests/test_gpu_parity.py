@@ -1059,15 +1059,17 @@ def test_fast_av_vels_flag_on_the_shipped_decks(lbm, digests, tmp_path, monkeypa
     assert np.allclose(av[steps], digests[name]["av_sample_values"], rtol=4e-3 if name == "1024x1024" else 5e-4)
 
 
-@pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 100), ("1024x1024_t200", 200), ("rand_64x48", 103)])
-def test_fast_av_vels_flag_against_the_oracle(lbm, oracle, digests, monkeypatch, name, steps):
-    """The same flag against the oracle's exact per-step sums: 1e-6 relative (observed ~1e-8), state bit-exact."""
-    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+@pytest.mark.parametrize("name,steps,kernel", [("synth_512x512_t100", 100, "multi"), ("1024x1024_t200", 200, "multi"), ("128x128", 203, "tile"),
+                                               ("256x256_t1000", 77, "tile"), ("128x128", 50, "multi")])
+def test_fast_av_vels_flag_against_the_oracle(lbm, oracle, digests, monkeypatch, name, steps, kernel):
+    """The same flag against the oracle's exact per-step sums: 1e-6 relative (observed ~5e-8), state bit-exact;
+    lbm_multi_kernel and lbm_tile_kernel (pair and one-cell-per-lane sub-steps)."""
+    if kernel == "multi":
+        monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
     p, obst, free = load_case(lbm, digests, name)
-    if p.nx % 64 or p.ny % 16:
-        pytest.skip("not a multi-kernel grid")
     exact = lbm.Simulation(p, obst)
     fast = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FAST_AVVELS)
+    assert f"lbm_{kernel}_kernel" in fast.partition.describe()["kernel"] and "fast av_vels" in fast.partition.describe()["kernel"]
     av_e, av_f = exact.run(steps), fast.run(steps)
     assert np.array_equal(bits(exact.local_cells()), bits(fast.local_cells()))
     exact.close()
