@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the kernel family on one GPU: every case runs the same deck through the
-library's own choice (lbm_multi_kernel / lbm_tile_kernel, random K / geometry) and through the one-step
+library's own choice (lbm_multi_kernel / lbm_tile_kernel, random K / geometry / tile width, 1-rank rings over the
+peer-to-peer and the RCCL loop, with and without LBM_FLAG_FAST_AVVELS) and through the one-step
 kernel (LBM_TUNE_MULTI_K=0, LBM_TUNE_TILE_MAX=0), and the final populations must agree bit for bit.
 No oracle involved (the one-step kernel is pinned to it by the test suite): thousands of cells x
 hundreds of shapes in a minute.
@@ -70,7 +71,8 @@ def run_partitions(p, obst, size, steps, kstep):
     return cells, (sums * np.float64(np.float32(1.0) / np.float32(free))).astype(np.float32)
 
 
-KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K", "LBM_TUNE_NARROW_MAX"]
+KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_MULTI_TILE",
+         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE"]
 
 
 def main(argv=None) -> int:
@@ -113,12 +115,14 @@ def fuzz(a) -> int:
             nx, ny = T * int(rng.integers(1, 20)), T * int(rng.integers(1, 20))
             if ny < 3:
                 ny = T * 2
-            env = {"LBM_TUNE_TILE_MAX": str(1 << 30), "LBM_TUNE_TILE_GEOM": str(T * 10 + int(rng.choice([4, 8]))), "LBM_TUNE_MULTI_K": "0"}
+            env = {"LBM_TUNE_TILE_MAX": str(1 << 30), "LBM_TUNE_TILE_GEOM": str(T * 10 + int(rng.choice([4, 8]))), "LBM_TUNE_MULTI_K": "0",
+                   "LBM_TUNE_TILE_SINGLE_MAX": str(rng.choice([0, 256, 512]))}        # x-pairs only / one cell per lane in the late sub-steps
         else:
             nx = 2 * int(rng.integers(64, 400 * a.scale)) if rng.random() < 0.7 else 64 * int(rng.integers(2, 12 * a.scale))
             ny = int(rng.integers(32, 300 * a.scale))
             K = int(rng.integers(1, 5))
-            env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K)}
+            env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K),
+                   "LBM_TUNE_MULTI_TILE": str(rng.choice([32, 64])), "LBM_P2P_SCHEDULE": str(rng.choice(["edge", "serial"]))}
         steps = int(rng.integers(1, 40))
         dens = float(rng.choice([0.0, 0.002, 0.05, 0.3]))
         p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])), float(rng.choice([0.7, 1.3, 1.85, 1.97])))
@@ -164,8 +168,10 @@ def fuzz(a) -> int:
             if variant == "fast":
                 os.environ.update(env)
                 flags = flags_fast
-                if kind == "ring":
-                    flags, kw = lbm._capi.FLAG_FORCE_HALO, {"exchange": "rccl"}
+                if kind == "ring":                                   # 1-rank ring over the peer-to-peer or the RCCL loop
+                    flags, kw = lbm._capi.FLAG_FORCE_HALO, {"exchange": str(rng.choice(["p2p", "rccl"])), "strict": True}
+                if kind in ("multi", "tile", "ring") and rng.random() < 0.3:
+                    flags |= lbm._capi.FLAG_FAST_AVVELS                # float sum|u| terms: populations must not move
             else:
                 os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
             s = lbm.Simulation(p, obst, flags=flags, **kw)
