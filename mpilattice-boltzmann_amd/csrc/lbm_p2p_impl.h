@@ -50,6 +50,7 @@ struct P2PPeer {
 
 struct lbm_p2p {
   lbm_ctx* ctx = nullptr;
+  int device = 0;                      // ctx's device, kept here: lbm_p2p_destroy must not depend on the context still existing
   int nranks = 1, rank = 0, south = 0, north = 0;
   hipStream_t compute = nullptr, edge = nullptr;
   hipEvent_t edge_done = nullptr, interior_done = nullptr;
@@ -141,6 +142,7 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   HIP_TRY(hipSetDevice(ctx->device));
   lbm_p2p* t = new lbm_p2p();
   t->ctx = ctx;
+  t->device = ctx->device;
   t->nranks = nranks;
   t->rank = rank;
   t->south = (rank + nranks - 1) % nranks;   // `top`    d2q9-bgk.c:245-246
@@ -311,9 +313,10 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
 int lbm_p2p_destroy(lbm_p2p* t)
 {
   if (!t) return 0;
-  if (t->ctx) (void)hipSetDevice(t->ctx->device);
+  // (every lbm_p2p_run returns with its streams drained; the compute stream belongs to the context, which may
+  // already be gone, so only what this object owns is touched here)
+  (void)hipSetDevice(t->device);
   if (t->edge) (void)hipStreamSynchronize(t->edge);
-  if (t->compute) (void)hipStreamSynchronize(t->compute);
   p2p_unmap(t);
   if (t->window) (void)hipFree(t->window);
   if (t->err) (void)hipHostFree(t->err);

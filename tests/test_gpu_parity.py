@@ -257,13 +257,22 @@ def test_full_size_8192_properties_and_short_parity(lbm, oracle):
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
     del cells
-    # the same deck as a K-step row partition on a 1-rank RCCL ring (what each rank of an N-GPU run executes)
-    ring = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
-    assert ring.partition.macro_steps >= 2
-    av_ring = ring.run(12)
-    assert np.array_equal(bits(ring.local_cells()), bits(ref_cells))
-    assert np.max(np.abs(av_ring - ref_exact) / ref_exact) < AV_EXACT_RTOL
-    ring.close()
+    # the same deck as a K-step row partition on a 1-rank ring (what each rank of an N-GPU run executes), both native loops;
+    # the state digest of the ring equals the digest of the plain run (lbm_state_checksum: 8 bytes instead of 2.4 GB)
+    digest = None
+    for exchange in ("p2p", "rccl"):
+        ring = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange=exchange, strict=True)
+        assert ring.partition.macro_steps >= 2 and ring.loop == exchange
+        av_ring = ring.run(12)
+        assert np.max(np.abs(av_ring - ref_exact) / ref_exact) < AV_EXACT_RTOL
+        if digest is None:
+            assert np.array_equal(bits(ring.local_cells()), bits(ref_cells))
+            digest = ring.partition.checksum()
+            half = ring.partition.checksum(0, n // 2) + ring.partition.checksum(n // 2, n)
+            assert half % (1 << 64) == digest                      # additive over disjoint row ranges
+        else:
+            assert ring.partition.checksum() == digest
+        ring.close()
 
 
 def test_mid_size_longer_run(lbm, oracle):
@@ -460,7 +469,9 @@ def test_tile_kernel_shapes_and_step_counts(lbm, oracle, monkeypatch, geom, nx, 
 
 
 @pytest.mark.parametrize("ranks,name,exchange", [(2, "128x256_t2000", "torch"), (3, "256x256_t1000", "torch"),
-                                                 (2, "256x256_t1000", "p2p"), (3, "1024x1024_t200", "p2p")])
+                                                 (2, "256x256_t1000", "p2p"), (3, "1024x1024_t200", "p2p"),
+                                                 # the four shipped decks in full (BASELINE.json configs) as multi-rank runs
+                                                 (2, "128x128", "p2p"), (3, "128x256", "p2p"), (4, "256x256", "p2p"), (4, "1024x1024", "p2p")])
 def test_several_ranks_share_the_gpu_over_gloo(lbm, digests, tmp_path, ranks, name, exchange):
     """The multi-process row-partitioned run end to end — torchrun, one process per rank, each with
     its own HIP partition, neighbour exchange, final reduction, rank-0 gather and output — on ONE GPU.
@@ -804,12 +815,13 @@ def test_fallback_to_the_torch_loop_when_the_native_loop_is_unavailable(lbm, ora
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
-def test_full_1024_deck_as_a_k_step_ring_matches_the_reference_file(lbm, digests, tmp_path):
+@pytest.mark.parametrize("exchange", ["p2p", "rccl"])
+def test_full_1024_deck_as_a_k_step_ring_matches_the_reference_file(lbm, digests, tmp_path, exchange):
     """All 20 000 steps of the shipped 1024x1024 deck through the row-partitioned code path (K-step
-    mode, native RCCL loop, 1-rank ring): final_state.dat must still be the reference binary's file."""
+    mode, native peer-to-peer / RCCL loop, 1-rank ring): final_state.dat must still be the reference binary's file."""
     name = "1024x1024"
     p, obst, free = load_case(lbm, digests, name)
-    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange=exchange, strict=True)
     assert sim.partition.macro_steps > 0
     av = sim.run()
     cells = sim.local_cells()
