@@ -41,13 +41,16 @@ struct P2PPushArgs {
   int* err;
 };
 
+// Polls are RELAXED system-scope loads of the uncached window (an acquire load per poll would invalidate this XCD's
+// caches on every iteration, under the feet of the launch running beside it); ONE acquire fence follows the last
+// of them.  What the flags guard is read by a later kernel of the stream in any case.
 __device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, const unsigned long long* parity_words, int nflags, unsigned long long epoch,
                                                unsigned long long parity, long long timeout_ticks, int* err)
 {
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   const long long t0 = wall_clock64();
   for (int f = 0; f < nflags; ++f) {
-    while (__hip_atomic_load(flags + f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
       if (wall_clock64() - t0 > timeout_ticks) {
         __hip_atomic_store(err, 1 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
@@ -59,7 +62,7 @@ __device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, 
       return;
     }
   }
-  __threadfence_system();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);                     // system scope
 }
 
 // My first K owned rows -> the south neighbour's top ghost rows, my last K owned rows -> the north
@@ -97,15 +100,17 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence_system();                                    // this block's rows are on their way before ...
+    // Release towards the peers, once per block: every wave's stores have left the CU at the barrier, this fence
+    // writes this XCD's L2 back (system scope) and completes before the arrival counter moves.  The block that
+    // sees every other block's arrival (acquire) therefore knows all rows are out, and raises the flags with plain
+    // write-through (system-scope, relaxed) stores: no second and third L2 write-back on the critical path.
+    __atomic_thread_fence(__ATOMIC_RELEASE);                   // system scope
     const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == gridDim.x - 1) {                               // ... the last block raises the flags
+    if (prev == gridDim.x - 1) {                               // the last block raises the flags
       __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      for (int d = 0; d < 2; ++d) {
-        __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      for (int d = 0; d < 2; ++d) __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_s_waitcnt(0);                           // parity words before flags (both write-through)
+      for (int d = 0; d < 2; ++d) __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // my own push does not depend on this wait, so a ring of ranks that all sit here cannot dead-lock: every
     // rank's flags are raised by blocks that never wait
