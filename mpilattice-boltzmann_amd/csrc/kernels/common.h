@@ -54,6 +54,35 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
+// N (a power of two, <= 8) per-lane values summed over the LANES (64, or the 32 low lanes of a half-filled wave) lanes
+// at once: at each of the first log2(N) levels a lane keeps half of its values and hands the other half to its
+// partner, so the N sums cost N-1 + (log2 LANES - log2 N) exchanges instead of N log2 LANES.  Afterwards lane L holds
+// the total of value L / (LANES / N) — lanes 0, LANES/N, 2 LANES/N, ... hold totals 0, 1, 2, ...  Fixed tree: deterministic.
+template <int N, int LANES = 64>
+__device__ __forceinline__ double wave_sum_multi(const double (&v)[N])
+{
+  static_assert((N == 1 || N == 2 || N == 4 || N == 8) && (LANES == 64 || LANES == 32), "power of two up to 8; whole or half wave");
+  const int lane = threadIdx.x & 63;
+  double cur[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) cur[i] = v[i];
+  int n = N, off = LANES / 2;
+#pragma unroll
+  for (; n > 1; n >>= 1, off >>= 1) {
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) {
+      const double mine = upper ? cur[i + n / 2] : cur[i];
+      const double theirs = upper ? cur[i] : cur[i + n / 2];
+      cur[i] = mine + __shfl_xor(theirs, off, 64);
+    }
+  }
+  double r = cur[0];
+#pragma unroll
+  for (; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+  return r;
+}
+
 // Deterministic block sum (fixed tree): every thread gets the total.
 __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 doubles */)
 {

@@ -210,10 +210,16 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
 
   // per-step sums over the owned cells of this tile: wave trees, then one lane per step over the waves
   const int ntiles = gridDim.x - 1;
-#pragma unroll
-  for (int i = 0; i < H; ++i) {
-    const double w = wave_sum(acc[i]);
-    if ((tid & 63) == 0) red[i * kWaves + (tid >> 6)] = w;
+  if ((tid | 63) < kLanes) {                     // wave-uniform: all 64 lanes of this wave exist
+    // all H sums of the wave in one butterfly: lane i * 64/H ends up with the total of step i
+    const double w = wave_sum_multi<H>(acc);
+    constexpr int kStride = 64 / H;
+    if ((tid & (kStride - 1)) == 0) red[((tid & 63) / kStride) * kWaves + (tid >> 6)] = w;
+  } else {                                       // the block's last wave is half full (288-lane geometries): the same on its 32 lanes
+    static_assert(kLanes % 64 == 0 || kLanes % 64 == 32, "whole or half last wave");
+    const double w = wave_sum_multi<H, 32>(acc);
+    constexpr int kStride = 32 / H;
+    if ((tid & (kStride - 1)) == 0) red[((tid & 31) / kStride) * kWaves + (tid >> 6)] = w;
   }
   __syncthreads();
   if (tid < k_total) {
