@@ -55,6 +55,7 @@ struct lbm_p2p {
   hipStream_t compute = nullptr, edge = nullptr;
   hipEvent_t edge_done = nullptr, interior_done = nullptr;
   bool edge_stream = true;             // edge rows on their own stream beside the interior launch
+  int push_blocks_edge = 16;           // blocks of the push kernel when it runs beside the interior launch (LBM_P2P_PUSH_BLOCKS)
   char* window = nullptr;              // my exported window: header + reduce slots [2][nranks][cap]
   size_t window_bytes = 0, reduce_cap = 0;
   const char* window_kind = "coarse";
@@ -121,7 +122,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
   const int work = 18 * (a.nfloats / 2);
   // at most 64 blocks (every block ends with an L2 write-back towards the peers), each lane moving up to four
   // float2's per pass
-  const dim3 grid(std::max(1, std::min(kP2PPushBlocks, (work + 1023) / 1024)));
+  const int max_blocks = t->edge_stream ? t->push_blocks_edge : kP2PPushBlocks;
+  const dim3 grid(std::max(1, std::min(max_blocks, (work + 1023) / 1024)));
   hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -157,6 +159,10 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
     if (std::string(sched) == "serial") t->edge_stream = false;
     if (std::string(sched) == "edge") t->edge_stream = true;
   }
+  // beside the interior launch the push has a whole macro-step to finish, and every block of it takes a CU slot and
+  // an L2 write-back away from that launch: us/step on a 1-rank ring of 8192 x 1024 rows for 8 / 12 / 16 / 32 / 64
+  // blocks 60.1 / 52.8 / 51.7 / 52.1 / 53.6 (8192 x 2048: 94.8 / - / 95.2 / 95.1 / 96.7)
+  t->push_blocks_edge = std::max(1, tune_env("LBM_P2P_PUSH_BLOCKS", 16));
   auto fail = [&]() { lbm_p2p_destroy(t); return 1; };
 #define P2P_TRY(expr)                                                                        \
   do {                                                                                       \
