@@ -450,6 +450,15 @@ def main() -> int:
         # of something the chip can actually deliver.  The 108-B convention figure (which assumes one pass over
         # HBM per step, while this kernel makes one per K steps) is reported beside it, not as `frac`.
         pmc = load_roofline(desc["kernel"], f"{nx}x{ny}") if (world == 1 and not args.ring) else None
+        # partitioned runs of the same kernel: the per-launch counters scale with the cells a launch advances (the PMC
+        # passes profile one process on the whole 8192x8192 grid; a rank's launches run the same code on fewer tiles)
+        scaled = None
+        if pmc is None and partitioned:
+            whole = load_roofline(desc["kernel"], "8192x8192")
+            if whole is not None:
+                scale = cells_per_launch * steps_per_launch / (8192.0 * 8192.0 * whole["steps_per_launch"])
+                scaled = dict(whole, hbm_bytes_per_launch=whole["hbm_bytes_per_launch"] * scale)
+                pmc = scaled
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": desc["kernel"], "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "steps_per_launch": steps_per_launch,
                 "convention_108B": {"GBps": algo_gbs, "ratio_to_peak": algo_gbs / HBM_PEAK_GBS, "bytes_per_cell_step": ALGO_BYTES_PER_CELL,
@@ -469,6 +478,7 @@ def main() -> int:
             roof.update(limits[bound])
             roof.update({"bound": bound, "traffic": pmc["hbm_bytes_per_launch"], "frac_hbm_physical": frac_hbm, "frac_valu": frac_valu,
                          "limits": limits, "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
+                         "scaled_from_single_gpu_pmc": scaled is not None,
                          "pmc_source": "profiles/r02/roofline.json (scripts/make_roofline.py over the rocprofv3 --pmc CSVs beside it)",
                          "note": "two limits, each a fraction of something the chip can deliver; achieved/peak/frac are those of the larger "
                                  "(`bound`).  hbm: physical bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) over THIS "
