@@ -5,7 +5,14 @@ ag14774/MPILattice-Boltzmann): hand-written gfx950 HIP kernels behind a C ABI
 The directory name contains a hyphen; import it as `mpilattice_boltzmann_amd` (alias module at the
 repo root) or via importlib.
 """
-from . import _capi, checker, decks
+import os as _os
+
+# The peer-to-peer transport maps other rank processes' device memory (hipIpcGetMemHandle / hipIpcOpenMemHandle) and
+# RCCL does the same; where the host driver only supports dmabuf IPC both need this set before the HIP runtime
+# initialises (harmless elsewhere).  Respect a value the caller has chosen.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from . import _capi, checker, decks  # noqa: E402
 from ._capi import EXPORTS, LIB_PATH, LIB_RCCL_PATH, P2P_EXPORTS, RCCL_EXPORTS, LbmError, load_library, load_rccl_library
 from .build import CLI as CLI_PATH
 from .build import build
