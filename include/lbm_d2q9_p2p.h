@@ -25,9 +25,11 @@
  *     lbm_p2p_connect(t, all_blobs);          verifies that every rank runs the same K-step layout
  *     lbm_p2p_run(t, n_steps, tot_u);         any number of times, the same n_steps on every rank
  *     lbm_p2p_destroy(t);
- * Contexts must come from lbm_create_rank (or lbm_create_global) and be in K-step mode
- * (lbm_macro_steps() > 0); ranks of one run call lbm_p2p_run concurrently (one host thread per rank when
- * several ranks share a process).
+ * Contexts come from lbm_create_rank (or lbm_create_global / lbm_create with LBM_FLAG_FORCE_HALO).  In K-step mode
+ * (lbm_macro_steps() > 0) the loop is the one above; runs that are not eligible for it (a rank with fewer than 32 rows,
+ * odd or short rows) step one at a time: the boundary launch stores the three populations that cross each cut straight
+ * into the neighbours' windows, one small kernel per step raises and awaits the flags.  Ranks of one run call
+ * lbm_p2p_run concurrently (one host thread per rank when several ranks share a process).
  */
 #ifndef LBM_D2Q9_P2P_H
 #define LBM_D2Q9_P2P_H

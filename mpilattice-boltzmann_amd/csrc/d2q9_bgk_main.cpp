@@ -122,8 +122,6 @@ int main(int argc, char* argv[])
     std::vector<char> handles(static_cast<size_t>(ngpus) * LBM_P2P_HANDLE_BYTES);
     for (int r = 0; r < ngpus; ++r) {
       if (lbm_rank_layout(&params, ngpus, r, flags, &lay[r])) die(lbm_last_error(), __LINE__, __FILE__);
-      if (lay[r].macro_k == 0)
-        die("LBM_GPUS: the peer-to-peer loop needs >= 32 rows per GPU and an even nx >= 128 (or a multiple of 64)", __LINE__, __FILE__);
       // the rows this rank needs: its own plus `ghost` rows below and above, wrapping (the scatter of :968-970)
       const int rows = lay[r].ny_local + 2 * lay[r].ghost;
       std::vector<int> window(static_cast<size_t>(rows) * nx);

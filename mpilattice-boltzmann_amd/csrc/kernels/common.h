@@ -27,6 +27,7 @@ struct StepArgs {
   float* send_south;           // row 0's populations 4,7,8 for the southern neighbour (next step)
   float* send_north;           // row nyl-1's populations 2,5,6 for the northern neighbour
   int nxp;                     // halo-buffer row pitch = nx + 2*kHaloGuard
+  int release_sends;           // the send buffers are a peer's memory: end the block with a system-scope release
   float omega;
   float accel_w1, accel_w2;    // d2q9-bgk.c:445-446
   int accel_row;               // local row that is global row ny-2, or -1: epilogue accelerate for the NEXT step

@@ -118,6 +118,23 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
   }
 }
 
+// One-step loop: "my halo messages of epoch e are complete" to both neighbours, then wait for theirs.  The messages
+// were stored into the neighbours' (uncached) windows by the kernel before this one in the stream.
+__global__ void __launch_bounds__(64) lbm_p2p_signal_wait_kernel(unsigned long long* flag_s, unsigned long long* flag_n, unsigned long long* parity_s,
+                                                                  unsigned long long* parity_n, const unsigned long long* wait_flags,
+                                                                  const unsigned long long* wait_parity, unsigned long long epoch, unsigned long long parity,
+                                                                  long long timeout_ticks, int* err)
+{
+  if (threadIdx.x != 0) return;
+  __atomic_thread_fence(__ATOMIC_RELEASE);                     // system scope
+  __hip_atomic_store(parity_s, parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(parity_n, parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_waitcnt(0);
+  __hip_atomic_store(flag_s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(flag_n, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  p2p_wait_flags(wait_flags, wait_parity, 2, epoch, parity, timeout_ticks, err);
+}
+
 // One wave: wait until every one of `nflags` flag words has reached `epoch` (acquire, system scope), at
 // most `timeout_ticks` of the 100 MHz wall clock; on time-out set *err (host-visible) to 1 + the index of
 // the missing flag.  With *err already set the kernel returns at once, so a failed run drains quickly.

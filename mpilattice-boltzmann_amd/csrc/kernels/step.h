@@ -263,7 +263,12 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
     if (r < n1 + n2) acc += step_quad<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
+  if (threadIdx.x == 0) {
+    a.partials_out[wblock] = acc;
+    // boundary launch of a peer-to-peer run: the outgoing halo rows were stored straight into the neighbours' windows;
+    // block_sum's barriers have drained every wave's stores, this writes the XCD's L2 back towards the peers
+    if (a.release_sends) __atomic_thread_fence(__ATOMIC_RELEASE);
+  }
 }
 
 // One cell per lane; the unit ranges of StepArgs are cell ranges here.
@@ -282,7 +287,10 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel_narrow(const StepArgs 
     if (r < n1 + n2) acc += step_cell<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) a.partials_out[wblock] = acc;
+  if (threadIdx.x == 0) {
+    a.partials_out[wblock] = acc;
+    if (a.release_sends) __atomic_thread_fence(__ATOMIC_RELEASE);      // see lbm_step_kernel
+  }
 }
 
 __device__ __forceinline__ void fold_previous(const StepArgs& a, double* red)

@@ -113,6 +113,7 @@ struct lbm_ctx {
   float* halo_alloc = nullptr;
   float* macro_pack[2] = {nullptr, nullptr};   // K-step mode: packed outgoing / incoming messages, [dir][plane][K*nx] each
   float* send[2] = {nullptr, nullptr};
+  bool release_sends = false;   // send[] point into peers' windows (one-step peer-to-peer loop)
   float* recv[2] = {nullptr, nullptr};
   double* partials[2] = {nullptr, nullptr};
   int partials_cap = 0;
@@ -928,6 +929,7 @@ int lbm_step_boundary(lbm_ctx* c, void* stream)
   a.north_halo = c->recv[1];
   a.send_south = c->send[0];
   a.send_north = c->send[1];
+  a.release_sends = c->release_sends ? 1 : 0;
   a.partials_out = c->partials[c->parity] + c->n_part_interior;
   a.prev_partials = c->partials[c->parity ^ 1];
   a.n_prev = c->n_prev;   // non-zero only when there was no interior launch to fold it

@@ -57,7 +57,7 @@ struct lbm_p2p {
   bool edge_stream = true;             // edge rows on their own stream beside the interior launch
   int push_blocks_edge = 16;           // blocks of the push kernel when it runs beside the interior launch (LBM_P2P_PUSH_BLOCKS)
   char* window = nullptr;              // my exported window: header + reduce slots [2][nranks][cap]
-  size_t window_bytes = 0, reduce_cap = 0;
+  size_t window_bytes = 0, reduce_cap = 0, halo_bytes = 0;   // halo_bytes: one-step mode's incoming messages, [2 parities][2 dirs][3 * nxp] floats
   const char* window_kind = "coarse";
   int* err = nullptr;                  // host-mapped error word written by the wait kernels
   unsigned int* done = nullptr;        // block-done counter of the push kernel
@@ -73,9 +73,15 @@ struct lbm_p2p {
 namespace {
 
 P2PWindowHeader* header_of(char* w) { return reinterpret_cast<P2PWindowHeader*>(w); }
-double* slot_of(char* w, size_t cap, int nranks, int parity, int r)
+double* slot_of(char* w, size_t halo_bytes, size_t cap, int nranks, int parity, int r)
 {
-  return reinterpret_cast<double*>(w + kP2PHeaderBytes) + (static_cast<size_t>(parity) * nranks + r) * cap;
+  return reinterpret_cast<double*>(w + kP2PHeaderBytes + halo_bytes) + (static_cast<size_t>(parity) * nranks + r) * cap;
+}
+// one-step mode: where the halo message of epoch parity `parity` arriving from direction `dir` (0 = from the south
+// neighbour) lies in a rank's window — three rows of nxp floats, as the step kernels read them (StepArgs::south_halo)
+float* halo_slot(char* w, int nxp, int parity, int dir)
+{
+  return reinterpret_cast<float*>(w + kP2PHeaderBytes) + static_cast<size_t>(parity * 2 + dir) * 3 * nxp;
 }
 
 void p2p_unmap(lbm_p2p* t)
@@ -129,6 +135,74 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
   return 0;
 }
 
+// MPI_Reduce (:396): all-gather of the per-step sums into every rank's window, local sum in rank order.
+int p2p_reduce(lbm_p2p* t, int n_steps, double* tot_u_per_step)
+{
+  lbm_ctx* c = t->ctx;
+  hipStream_t cs = t->compute;
+  for (int t0 = 0; t0 < n_steps; t0 += static_cast<int>(t->reduce_cap)) {
+    const int n = std::min(n_steps - t0, static_cast<int>(t->reduce_cap));
+    const unsigned long long round = ++t->reduce_round;
+    const int par = static_cast<int>(round & 1);
+    hipLaunchKernelGGL(lbm_p2p_gather_kernel, dim3((n + 255) / 256, t->nranks), dim3(256), 0, cs, c->sums + t0, n, t->d_slots + static_cast<size_t>(par) * t->nranks);
+    hipLaunchKernelGGL(lbm_p2p_reduce_signal_kernel, dim3(1), dim3(64), 0, cs, t->d_flags, t->nranks, round);
+    hipLaunchKernelGGL(lbm_p2p_wait_kernel, dim3(1), dim3(64), 0, cs, header_of(t->window)->reduce_flag, static_cast<const unsigned long long*>(nullptr),
+                       t->nranks, round, 0ull, t->timeout_ticks, t->err);
+    hipLaunchKernelGGL(lbm_p2p_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, cs, slot_of(t->window, t->halo_bytes, t->reduce_cap, t->nranks, par, 0), t->reduce_cap,
+                       t->nranks, n, t->reduce_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+  }
+  return 0;
+}
+
+int p2p_check_error(lbm_p2p* t)
+{
+  if (*t->err == 0) return 0;
+  const int e = *t->err;
+  const char* who = e >= 100 ? "a neighbour's grids are out of step with this rank's (different number of steps run ?)"
+                             : "a peer's data did not arrive in time (peer failed or never started the run ?)";
+  lbm_internal::set_error("lbm_p2p_run: rank " + std::to_string(t->rank) + ": " + who + " [code " + std::to_string(e) + "]");
+  return 1;
+}
+
+// One-step mode (contexts that are not eligible for K-step mode: fewer than 32 rows on some rank, odd or short rows):
+// the three populations that cross each cut travel every step, stored by the boundary launch straight into the
+// neighbours' windows (their `south_halo` / `north_halo` of the next step), two slots per direction by epoch parity.
+//   [signal + wait kernel: my messages of step t are out; theirs have arrived]   MPI_Startall / MPI_Waitall (:327,364)
+//   interior rows t (:350), boundary rows t (:365-366) -> writes the messages of step t+1
+int p2p_run_one_step(lbm_p2p* t, int n_steps, double* tot_u_per_step)
+{
+  lbm_ctx* c = t->ctx;
+  hipStream_t cs = t->compute;
+  const int nxp = c->nxp;
+  P2PPeer& ps = t->peers[t->south];
+  P2PPeer& pn = t->peers[t->north];
+  auto bind = [&](unsigned long long e_recv, unsigned long long e_send) {
+    c->recv[0] = halo_slot(t->window, nxp, static_cast<int>(e_recv & 1), 0);
+    c->recv[1] = halo_slot(t->window, nxp, static_cast<int>(e_recv & 1), 1);
+    c->send[0] = halo_slot(ps.window, nxp, static_cast<int>(e_send & 1), 1);   // my southward rows are the south neighbour's NORTH halo
+    c->send[1] = halo_slot(pn.window, nxp, static_cast<int>(e_send & 1), 0);
+  };
+  c->release_sends = true;
+  unsigned long long epoch = t->epoch + 1;
+  bind(epoch, epoch);
+  if (lbm_step_prepare(c, n_steps, cs)) return 1;              // step-0 accelerate_flow + the messages of the first step
+  P2PWindowHeader* mine = header_of(t->window);
+  for (int step = 0; step < n_steps; ++step, ++epoch) {
+    hipLaunchKernelGGL(lbm_p2p_signal_wait_kernel, dim3(1), dim3(64), 0, cs, &header_of(ps.window)->halo_flag[1], &header_of(pn.window)->halo_flag[0],
+                       &header_of(ps.window)->halo_parity[2 * 1 + (epoch & 1ull)], &header_of(pn.window)->halo_parity[2 * 0 + (epoch & 1ull)],
+                       mine->halo_flag, mine->halo_parity, epoch, static_cast<unsigned long long>(c->cur), t->timeout_ticks, t->err);
+    HIP_TRY(hipGetLastError());
+    bind(epoch, epoch + 1);
+    if (lbm_step_interior(c, cs) || lbm_step_boundary(c, cs) || lbm_step_finish(c, cs)) return 1;
+  }
+  t->epoch = epoch - 1;
+  if (p2p_reduce(t, n_steps, tot_u_per_step)) return 1;
+  return p2p_check_error(t);
+}
+
 }  // namespace
 
 extern "C" {
@@ -137,8 +211,8 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
 {
   if (!out || !ctx || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) { lbm_internal::set_error("lbm_p2p_create: bad argument (1..64 ranks)"); return 1; }
   *out = nullptr;
-  if (ctx->ghost == 0 || ctx->multi_K == 0) {
-    lbm_internal::set_error("lbm_p2p_create: the context is not in K-step mode (lbm_create_rank / lbm_create_global; lbm_macro_steps() > 0)");
+  if (ctx->self_periodic) {
+    lbm_internal::set_error("lbm_p2p_create: the context is a self-contained periodic domain (create it with lbm_create_rank, or with LBM_FLAG_FORCE_HALO)");
     return 1;
   }
   HIP_TRY(hipSetDevice(ctx->device));
@@ -177,7 +251,8 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   // exported window: flags + reduce slots.  Uncached device memory, so that a flag raised by a peer is seen
   // by a kernel that is already running here; fine-grained, then ordinary memory as fall-backs.
   t->reduce_cap = static_cast<size_t>(std::max(ctx->p.max_iters, 4096));
-  t->window_bytes = kP2PHeaderBytes + sizeof(double) * 2 * nranks * t->reduce_cap;
+  t->halo_bytes = round_up(sizeof(float) * 2 * 2 * 3 * static_cast<size_t>(ctx->nxp), 256);
+  t->window_bytes = kP2PHeaderBytes + t->halo_bytes + sizeof(double) * 2 * nranks * t->reduce_cap;
   void* w = nullptr;
   if (tune_env("LBM_P2P_WINDOW", 0) <= 0 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocUncached) == hipSuccess) t->window_kind = "uncached";
   else if (tune_env("LBM_P2P_WINDOW", 0) <= 1 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocFinegrained) == hipSuccess) t->window_kind = "fine-grained";
@@ -302,12 +377,13 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
   }
   // the edge stream exists only where the schedule uses it: every stream takes a share of the process's few
   // hardware queues, and ranks of one process on one device must not share a queue (see above)
+  if (c->ghost == 0) t->edge_stream = false;               // one-step mode runs on the compute stream
   if (t->edge_stream && !t->edge) HIP_TRY(hipStreamCreateWithFlags(&t->edge, hipStreamNonBlocking));
   // device tables for the reduce kernels: where my sums go in every rank's window, and my flag there
   std::vector<double*> slots(static_cast<size_t>(2) * t->nranks);
   std::vector<unsigned long long*> flags(t->nranks);
   for (int r = 0; r < t->nranks; ++r) {
-    for (int par = 0; par < 2; ++par) slots[static_cast<size_t>(par) * t->nranks + r] = slot_of(t->peers[r].window, t->reduce_cap, t->nranks, par, t->rank);
+    for (int par = 0; par < 2; ++par) slots[static_cast<size_t>(par) * t->nranks + r] = slot_of(t->peers[r].window, t->halo_bytes, t->reduce_cap, t->nranks, par, t->rank);
     flags[r] = &header_of(t->peers[r].window)->reduce_flag[t->rank];
   }
   HIP_TRY(hipMemcpy(t->d_slots, slots.data(), sizeof(double*) * slots.size(), hipMemcpyHostToDevice));
@@ -344,6 +420,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
   if (n_steps == 0) return 0;
   lbm_ctx* c = t->ctx;
   HIP_TRY(hipSetDevice(c->device));
+  if (c->ghost == 0) return p2p_run_one_step(t, n_steps, tot_u_per_step);
   const int K = c->multi_K;
   hipStream_t cs = t->compute, es = t->edge_stream ? t->edge : t->compute;
   if (begin_run(c, n_steps, cs)) return 1;                     // step-0 accelerate_flow (d2q9-bgk.c:345-348)
@@ -394,29 +471,9 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
   c->ev_launches = c->ev_tile_launches;
   c->ev_valid = true;
   if (fold_last(c, cs)) return 1;
-  // MPI_Reduce (:396): all-gather of the per-step sums into every rank's window, local sum in rank order
-  for (int t0 = 0; t0 < n_steps; t0 += static_cast<int>(t->reduce_cap)) {
-    const int n = std::min(n_steps - t0, static_cast<int>(t->reduce_cap));
-    const unsigned long long round = ++t->reduce_round;
-    const int par = static_cast<int>(round & 1);
-    hipLaunchKernelGGL(lbm_p2p_gather_kernel, dim3((n + 255) / 256, t->nranks), dim3(256), 0, cs, c->sums + t0, n, t->d_slots + static_cast<size_t>(par) * t->nranks);
-    hipLaunchKernelGGL(lbm_p2p_reduce_signal_kernel, dim3(1), dim3(64), 0, cs, t->d_flags, t->nranks, round);
-    hipLaunchKernelGGL(lbm_p2p_wait_kernel, dim3(1), dim3(64), 0, cs, header_of(t->window)->reduce_flag, static_cast<const unsigned long long*>(nullptr),
-                       t->nranks, round, 0ull, t->timeout_ticks, t->err);
-    hipLaunchKernelGGL(lbm_p2p_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, cs, slot_of(t->window, t->reduce_cap, t->nranks, par, 0), t->reduce_cap,
-                       t->nranks, n, t->reduce_out);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n, hipMemcpyDeviceToHost, cs));
-    HIP_TRY(hipStreamSynchronize(cs));
-  }
+  if (p2p_reduce(t, n_steps, tot_u_per_step)) return 1;
   if (t->edge_stream) HIP_TRY(hipStreamSynchronize(es));
-  if (*t->err != 0) {
-    const int e = *t->err;
-    const char* who = e >= 100 ? "a neighbour's grids are out of step with this rank's (different number of steps run ?)"
-                               : "a peer's data did not arrive in time (peer failed or never started the run ?)";
-    lbm_internal::set_error("lbm_p2p_run: rank " + std::to_string(t->rank) + ": " + who + " [code " + std::to_string(e) + "]");
-    return 1;
-  }
+  if (p2p_check_error(t)) return 1;
   return 0;
 }
 
@@ -425,6 +482,10 @@ int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)
   if (!t || !text || len == 0) { lbm_internal::set_error("lbm_p2p_describe: null argument"); return 1; }
   const char* reach = "self";
   if (t->nranks > 1) reach = (t->connected && t->peers[t->north].ipc) ? "ipc" : "in-process";
+  if (t->ctx->ghost == 0) {
+    std::snprintf(text, len, "window %s; neighbours %s; one-step mode", t->window_kind, reach);
+    return 0;
+  }
   std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d", t->window_kind, reach, t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K);
   return 0;
 }

@@ -595,11 +595,11 @@ class Simulation:
 
     With a torch.distributed process group of size > 1 (one process per GPU), each rank owns the rows
     `rank_layout()` gives it and `run()` performs the halo exchange — `loop` tells which way:
-      "p2p"    native loop, direct peer-to-peer stores into the neighbours' ghost rows (K-step mode only)
+      "p2p"    native loop, direct peer-to-peer stores into the neighbours' ghost rows (K-step mode) or halo slots (one-step mode)
       "rccl"   native loop of liblbm_d2q9_rccl.so, RCCL send/recv (K-step or one-step mode)
       "torch"  one-step loop driven from Python over torch.distributed P2P ops
       "single" the whole grid on one GPU, one `lbm_run`.
-    `exchange="auto"` picks p2p when the run is in K-step mode, else rccl.  With strict=False a native loop
+    `exchange="auto"` = p2p.  With strict=False a native loop
     that cannot be set up on every rank falls back to the next one (with a warning); with strict=True that
     is an error — what ran is always `loop`, never the request."""
 
@@ -657,11 +657,6 @@ class Simulation:
         for loop in order:
             one_step = _capi.FLAG_ONE_STEP if loop == "torch" else 0
             self._make_partition(flags | one_step, free_cells)
-            if loop == "p2p" and self.partition.macro_steps == 0:
-                last_err = "the run is not in K-step mode (a rank has < 32 rows, or nx is odd / < 128)"
-                if exchange == "p2p" and strict:
-                    break
-                continue                      # a layout fact, the same on every rank: not a failure
             try:
                 if loop == "p2p":
                     self._p2p = P2PRing(self.partition, group) if distributed else P2PRing.local_ring([self.partition])[0]

@@ -41,6 +41,7 @@ def main() -> int:
         assert sim.loop == "p2p" and "ipc" in sim.describe()["p2p"], sim.describe()
         if c.get("K"):
             assert sim.partition.macro_steps == c["K"]
+        assert ("one-step" in sim.describe()["p2p"]) == (sim.partition.macro_steps == 0)
         av = np.concatenate([sim.run(n) for n in c["runs"]])
         everyone = [None] * size
         dist.all_gather_object(everyone, av.tobytes())

@@ -835,6 +835,24 @@ def test_full_1024_deck_as_a_k_step_ring_matches_the_reference_file(lbm, digests
 
 # ---- peer-to-peer halo transport (include/lbm_d2q9_p2p.h) ---------------------------------------------
 
+@pytest.mark.parametrize("name", ["tiny_8x3", "rand_64x48", "walls_40x24", "wide_256x8", "tall_8x256", "column_24x20", "128x128"])
+def test_p2p_ring_of_one_in_one_step_mode(lbm, oracle, digests, monkeypatch, name, kernel_form):
+    """The peer-to-peer loop for runs that are not eligible for K-step mode (here: forced off, or shapes that never
+    are — 3 rows, 8-cell rows, odd sizes): the boundary launch stores its outgoing populations straight into the
+    neighbour's window (the rank's own, on a 1-rank ring), one kernel per step raises and awaits the flags."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", "0")
+    p, obst, free = load_case(lbm, digests, name)
+    steps = min(p.max_iters, 70)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="p2p", strict=True)
+    assert sim.loop == "p2p" and sim.partition.macro_steps == 0 and "one-step" in sim.describe()["p2p"]
+    av = np.concatenate([sim.run(steps - 7), sim.run(7)])
+    cells = sim.local_cells()
+    sim.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 4])
 @pytest.mark.parametrize("schedule", ["edge", "serial"])
 @pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 61), ("128x128", 50), ("1024x1024_t200", 31)])
@@ -862,7 +880,10 @@ P2P_CASES = {
     3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
         dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True)],
     4: [dict(nx=256, ny=131, K=3, schedule="edge", runs=[31]), dict(nx=128, ny=260, K=4, schedule="serial", runs=[17, 14]),
-        dict(nx=2048, ny=4100, K=0, schedule="", runs=[7], scatter=True, p=0.005)],
+        dict(nx=2048, ny=4100, K=0, schedule="", runs=[7], scatter=True, p=0.005),
+        # one-step mode: 12 / 11-row ranks, an odd row length, a 3-row last rank (d2q9-bgk.c:848-849)
+        dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=37, ny=45, K=0, schedule="", runs=[19], scatter=True),
+        dict(nx=16, ny=9, K=0, schedule="", runs=[30])],
 }
 
 
@@ -953,7 +974,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     assert out["launch_attempts"][0]["returncode"] == 0
 
 
-@pytest.mark.parametrize("gpus,name", [(2, "256x256_t1000"), (3, "1024x1024_t200"), (4, "128x256_t2000")])
+@pytest.mark.parametrize("gpus,name", [(2, "256x256_t1000"), (3, "1024x1024_t200"), (4, "128x256_t2000"), (4, "rand_64x48"), (3, "tall_8x256")])
 def test_cli_drives_several_ranks_from_one_process(lbm, digests, tmp_path, gpus, name):
     """LBM_GPUS=N: the C shim as a single-process multi-GPU host — N ranks of the reference's decomposition, one
     host thread each, peer-to-peer halos.  Here all ranks sit on device 0 (LBM_DEVICES), the way a one-GPU box
