@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Per-step timing of the step path in its different forms on one GPU (tuning aid, not the bench).
 
-    python scripts/measure.py --grid 8192x8192 --steps 200 [--mode single|ring|ring-torch] [--flags N]
+    python scripts/measure.py --grid 8192x8192 --steps 200 [--mode single|ring|ring-rccl|ring-torch] [--flags N]
 
-`ring` runs the row-partitioned code path (interior + boundary kernels, RCCL exchange on the side
+`ring` / `ring-rccl` run the row-partitioned code path (interior + edge launches, peer-to-peer or RCCL exchange on a side
 stream) on a 1-rank ring, which is what one rank of an N-GPU run executes per step for a grid of
 this size: e.g. --grid 8192x1024 is one rank's share of the 8192x8192 deck on 8 GPUs."""
 import argparse
@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--grid", default="8192x8192", help="NXxNY")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mode", default="single", choices=["single", "ring", "ring-torch"])
+    ap.add_argument("--mode", default="single", choices=["single", "ring", "ring-rccl", "ring-torch"],
+                    help="ring = 1-rank ring over the peer-to-peer loop, ring-rccl over the RCCL loop, ring-torch over torch.distributed")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=3)
     a = ap.parse_args()
@@ -40,6 +41,8 @@ def main():
         dist.init_process_group("nccl", init_method="file:///tmp/measure_rdv_%d" % os.getpid(), rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
         kw = dict(distributed=True, exchange="torch")
+    elif a.mode != "single":
+        kw = dict(exchange="rccl" if a.mode == "ring-rccl" else "p2p", strict=True)
     sim = lbm.Simulation(p, obst, flags=flags, **kw)
     sim.run(a.warmup)
     best = None
