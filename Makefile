@@ -9,7 +9,7 @@ REF_AV_VELS_FILE=tests/golden/check/128x128.av_vels.dat.gz
 
 all: $(EXE)
 
-$(EXE): mpilattice-boltzmann_amd/csrc/*.hip mpilattice-boltzmann_amd/csrc/*.cpp mpilattice-boltzmann_amd/csrc/*.h mpilattice-boltzmann_amd/csrc/kernels/*.h include/*.h
+$(EXE): mpilattice-boltzmann_amd/csrc/*.hip mpilattice-boltzmann_amd/csrc/*.cpp mpilattice-boltzmann_amd/csrc/*.c mpilattice-boltzmann_amd/csrc/*.h mpilattice-boltzmann_amd/csrc/kernels/*.h include/*.h
 	python3 -c "import __graft_entry__ as g; g.build()"
 	ln -sf mpilattice-boltzmann_amd/bin/d2q9-bgk $(EXE)
 

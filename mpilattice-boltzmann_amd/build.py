@@ -58,9 +58,14 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    cli_src = [os.path.join(CSRC, "d2q9_bgk_main.cpp")]
+    cli_src = [os.path.join(CSRC, "d2q9_bgk_main.c")]
     if force or _stale(CLI, cli_src + headers + [LIB]):
-        cmd = [hipcc, *COMMON, *cli_src, "-L", os.path.dirname(LIB), "-llbm_d2q9", "-Wl,-rpath,$ORIGIN/../lib", "-o", CLI]
+        # the host shim is plain C99 over the C ABI: the system C compiler, no HIP, no C++ runtime of its own
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if cc is None:
+            raise RuntimeError("no C compiler (gcc / cc) for the host shim")
+        cmd = [cc, "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-pthread", "-I", os.path.join(ROOT, "include"), *cli_src,
+               "-L", os.path.dirname(LIB), "-llbm_d2q9", "-Wl,-rpath,$ORIGIN/../lib", "-o", CLI]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
