@@ -121,15 +121,38 @@ float lbm_av_velocity_host(const lbm_params* p, const float* cells, const int* o
   return tot_u;
 }
 
-// The same sum from device-computed u_x, u_y (lbm_get_observables): :748 in the reference's cell order.
+// The same sum from device-computed u_x, u_y (lbm_get_observables): :748 in the reference's cell order.  The float
+// accumulator makes the ORDER of the additions part of the result, so they stay serial; the double square roots
+// (67 M of them at 8192x8192) do not depend on one another and are taken by several threads, a block of cells at a time.
 float lbm_av_velocity_obs(const lbm_params* p, const float* obs, const int* obstacles, int rows)
 {
   float tot_u = 0.0f;
   const size_t n = static_cast<size_t>(rows) * static_cast<size_t>(p->nx);
-  for (size_t c = 0; c < n; ++c) {
-    if (obstacles[c]) continue;                                                 // :721
-    const float ux = obs[4 * c], uy = obs[4 * c + 1];
-    tot_u += std::sqrt(static_cast<double>((ux * ux) + (uy * uy)));            // :748
+  const size_t block = size_t(1) << 20;
+  unsigned workers = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+  if (n < block) workers = 1;
+  std::vector<double> term(std::min(n, block));
+  for (size_t c0 = 0; c0 < n; c0 += block) {
+    const size_t m = std::min(block, n - c0);
+    auto roots = [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        const float ux = obs[4 * (c0 + i)], uy = obs[4 * (c0 + i) + 1];
+        term[i] = std::sqrt(static_cast<double>((ux * ux) + (uy * uy)));       // :748
+      }
+    };
+    if (workers == 1) {
+      roots(0, m);
+    } else {
+      std::vector<std::thread> pool;
+      const size_t per = (m + workers - 1) / workers;
+      for (unsigned w = 0; w < workers; ++w) {
+        const size_t lo = std::min(m, w * per), hi = std::min(m, lo + per);
+        if (lo < hi) pool.emplace_back(roots, lo, hi);
+      }
+      for (std::thread& t : pool) t.join();
+    }
+    for (size_t i = 0; i < m; ++i)
+      if (!obstacles[c0 + i]) tot_u += term[i];                                // :721, :748 — float += double, as the reference
   }
   return tot_u;
 }

@@ -210,6 +210,19 @@ def test_observables_writer_and_reynolds_equal_the_cells_path(lbm, oracle, tmp_p
     lbm.write_final_state_obs(b, p, obs, obst, displ=3)
     assert open(a, "rb").read() == open(b, "rb").read()
     assert lbm.av_velocity_obs(p, obs, obst) == lbm.av_velocity_host(p, cells, obst) == oracle.av_velocity_sum(p, cells, obst)
+    # more than one block of cells: the square roots are taken by several threads, the float accumulation stays serial
+    big = lbm.Params(1500, 1100, 3, 7, 0.1, 0.005, 1.3)
+    cb = (rng.random((1100, 1500, 9), dtype=np.float32) * 0.02 + 0.005).astype(np.float32)
+    ob = (rng.random((1100, 1500)) < 0.1).astype(np.int32)
+    rho = cb.sum(axis=-1, dtype=np.float32)          # any positive density will do for this comparison
+    ux = ((cb[..., 1] + cb[..., 5] + cb[..., 8] - (cb[..., 3] + cb[..., 6] + cb[..., 7])) / rho).astype(np.float32)
+    uy = ((cb[..., 2] + cb[..., 5] + cb[..., 6] - (cb[..., 4] + cb[..., 7] + cb[..., 8])) / rho).astype(np.float32)
+    ob4 = np.stack([ux, uy, ux, ux], axis=-1).astype(np.float32)
+    acc = np.float32(0.0)
+    terms = np.sqrt((ux * ux + uy * uy).astype(np.float64))
+    for v in terms[ob == 0]:
+        acc = np.float32(np.float64(acc) + v)
+    assert lbm.av_velocity_obs(big, ob4, ob) == float(acc)
 
 
 def test_writers_and_epilogue_match_the_oracle(lbm, oracle, tmp_path):
