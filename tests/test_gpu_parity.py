@@ -759,15 +759,16 @@ def test_randomised_kernel_cross_check(lbm):
 
 
 @pytest.mark.parametrize("K", [2, 3, 4])
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 @pytest.mark.parametrize("nx,ny", [(206, 142), (130, 37), (650, 62)])
-def test_k_step_ring_message_sizes(lbm, oracle, monkeypatch, nx, ny, K):
+def test_k_step_ring_message_sizes(lbm, oracle, monkeypatch, nx, ny, K, exchange):
     """K*nx floats per plane and direction travel in the packed halo message; K = 3 with nx = 206 / 130 /
     650 makes that count 2 mod 4 (a float4 copy loop once dropped the last two floats of such a message
     and overran into the first owned row).  Found by scripts/fuzz_kernels.py."""
     monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
     p = lbm.Params(nx, ny, 20, 4, 0.1, 0.05, 1.85)
     obst = lbm.synthetic_obstacles(nx, ny, 0.05, nx + ny, False)
-    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange=exchange, strict=True)
     assert sim.partition.macro_steps == K
     av = np.concatenate([sim.run(2), sim.run(18)])
     cells = sim.local_cells()
@@ -777,11 +778,12 @@ def test_k_step_ring_message_sizes(lbm, oracle, monkeypatch, nx, ny, K):
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 @pytest.mark.parametrize("nx,ny", [(200, 150), (130, 37), (1000, 125)])
-def test_k_step_ring_of_one_with_odd_rows(lbm, oracle, nx, ny):
+def test_k_step_ring_of_one_with_odd_rows(lbm, oracle, nx, ny, exchange):
     p = lbm.Params(nx, ny, 40, 4, 0.1, 0.01, 1.7)
     obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx + ny, False)
-    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="rccl")
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange=exchange, strict=True)
     assert sim.partition.macro_steps > 0
     av = sim.run(40)
     ref_cells, _, ref_exact = oracle.run(p, obst, 40, nthreads=4)
