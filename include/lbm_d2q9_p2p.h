@@ -24,7 +24,7 @@
  *     [all-gather the blobs in rank order]
  *     lbm_p2p_connect(t, all_blobs);          verifies that every rank runs the same K-step layout
  *     lbm_p2p_run(t, n_steps, tot_u);         any number of times, the same n_steps on every rank
- *     lbm_p2p_destroy(t);
+ *     lbm_p2p_disconnect(t);  [barrier]  lbm_p2p_destroy(t);  lbm_destroy(ctx);
  * Contexts come from lbm_create_rank (or lbm_create_global / lbm_create with LBM_FLAG_FORCE_HALO).  In K-step mode
  * (lbm_macro_steps() > 0) the loop is the one above; runs that are not eligible for it (a rank with fewer than 32 rows,
  * odd or short rows) step one at a time: the boundary launch stores the three populations that cross each cut straight
@@ -47,6 +47,10 @@ typedef struct lbm_p2p lbm_p2p;     /* opaque: exported window, mapped peers, st
 int lbm_p2p_create(lbm_p2p** t, lbm_ctx* ctx, int nranks, int rank);
 int lbm_p2p_handle(lbm_p2p* t, void* blob /* LBM_P2P_HANDLE_BYTES */);
 int lbm_p2p_connect(lbm_p2p* t, const void* blobs /* nranks * LBM_P2P_HANDLE_BYTES, rank order */);
+/* Unmap every peer's memory (the converse of lbm_p2p_connect).  Memory that another process has mapped must not be freed
+ * before that process has unmapped it: ranks in separate processes call lbm_p2p_disconnect, meet at a barrier of the
+ * caller's, and only then lbm_p2p_destroy / lbm_destroy (which free what the others had mapped). */
+int lbm_p2p_disconnect(lbm_p2p* t);
 int lbm_p2p_destroy(lbm_p2p* t);
 
 /* n_steps iterations of d2q9-bgk.c:315-378 for this rank, then the reduction of :396: tot_u_per_step (host,

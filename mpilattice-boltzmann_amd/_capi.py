@@ -98,6 +98,7 @@ _P2P_SIGNATURES = {
     "lbm_p2p_create": (C.c_int, [_P(C.c_void_p), _ctx, C.c_int, C.c_int]),
     "lbm_p2p_handle": (C.c_int, [C.c_void_p, C.c_char_p]),
     "lbm_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "lbm_p2p_disconnect": (C.c_int, [C.c_void_p]),
     "lbm_p2p_destroy": (C.c_int, [C.c_void_p]),
     "lbm_p2p_run": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
     "lbm_p2p_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),

@@ -392,6 +392,16 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
   return 0;
 }
 
+int lbm_p2p_disconnect(lbm_p2p* t)
+{
+  if (!t) return 0;
+  (void)hipSetDevice(t->device);
+  if (t->edge) (void)hipStreamSynchronize(t->edge);
+  p2p_unmap(t);
+  t->connected = false;
+  return 0;
+}
+
 int lbm_p2p_destroy(lbm_p2p* t)
 {
   if (!t) return 0;

@@ -484,6 +484,7 @@ class P2PRing:
             rank, size = dist.get_rank(group), dist.get_world_size(group)
         self.rank, self.size = rank, size
         self._group = group
+        self._connected_over_group = False
         # every rank reaches the all-gather below whether or not its own set-up worked: a failure is
         # carried in place of the handle and raised on all ranks together
         blob, err = None, None
@@ -505,6 +506,7 @@ class P2PRing:
                 self.close()
                 raise LbmError("peer-to-peer set-up failed on rank(s) " + "; ".join(f"{r}: {m}" for r, m in bad))
             self.connect(box)
+            self._connected_over_group = size > 1
             # nobody starts pushing rows into a neighbour that has not mapped its peers yet
             dist.barrier(group=group)
         elif err is not None:
@@ -557,9 +559,20 @@ class P2PRing:
         return out[:n_steps]
 
     def close(self) -> None:
-        if getattr(self, "_t", None) is not None and self._t:
-            self._lib.lbm_p2p_destroy(self._t)
-            self._t = C.c_void_p()
+        """Unmap the peers, meet the other ranks (memory another process has mapped must not be freed before that
+        process has unmapped it), then free this rank's window.  The caller frees the partition afterwards."""
+        if getattr(self, "_t", None) is None or not self._t:
+            return
+        self._lib.lbm_p2p_disconnect(self._t)
+        if self._connected_over_group:
+            try:
+                import torch.distributed as dist
+                if dist.is_initialized():
+                    dist.barrier(group=self._group)
+            except Exception:       # noqa: BLE001 - the group is gone (interpreter shutdown, failed peer): nothing to meet
+                pass
+        self._lib.lbm_p2p_destroy(self._t)
+        self._t = C.c_void_p()
 
     def __del__(self):
         try:

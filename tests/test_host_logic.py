@@ -29,7 +29,8 @@ def test_p2p_entry_points_are_exported_by_the_core_library(lbm):
     header = open(os.path.join(ROOT, "include", "lbm_d2q9_p2p.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(lbm_p2p_[a-z_0-9]+)\s*\(", header))
-    assert declared == {"lbm_p2p_create", "lbm_p2p_handle", "lbm_p2p_connect", "lbm_p2p_destroy", "lbm_p2p_run", "lbm_p2p_describe"}
+    assert declared == {"lbm_p2p_create", "lbm_p2p_handle", "lbm_p2p_connect", "lbm_p2p_disconnect", "lbm_p2p_destroy", "lbm_p2p_run",
+                        "lbm_p2p_describe"}
     nm = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert declared <= set(re.findall(r" T (lbm_[a-z_0-9]+)", nm))
     assert declared == set(lbm.P2P_EXPORTS)
