@@ -34,6 +34,9 @@ struct TileGeom {
   static constexpr int R = T + 2 * H;
   static constexpr int RP = R / 2;                  // aligned pairs per region row
   static constexpr int cells = R * R;
+  // (a lane per region CELL, R*R lanes, so that every sub-step can deal one cell per lane, was measured and dropped:
+  // 256x256 deck 0.142 -> 0.204 s, 128x128 0.0529 -> 0.0554 — sixteen-wave blocks pay more at the barriers than the
+  // shorter chains of the early sub-steps save)
   static constexpr int lanes = RP * R;
   static constexpr int waves = (lanes + 63) / 64;
   static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * cells + sizeof(double) * H * waves + cells;   // + flag bytes
@@ -60,7 +63,7 @@ struct TileArgs {
 };
 
 template <int T, int H, bool FULL, bool FAST>   // FULL: this launch does exactly H steps (region sizes are compile-time constants); FAST: float sum|u| terms
-__global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel(const TileArgs a)
+__global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const TileArgs a)
 {
   using G = TileGeom<T, H>;
   constexpr int R = G::R, RP = G::RP, kCells = G::cells, kLanes = G::lanes, kWaves = G::waves;
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__((T + 2 * H) * (T + 2 * H) / 2) lbm_tile_kernel
 
   // ---- load: lane = one aligned x-pair of the region, periodic (d2q9-bgk.c:527-529 in x; :245-247 one-rank ring
   // in y); nx, T and H are even, so a pair never straddles the wrap and its first cell has an even index
-  {
+  if (tid < RP * R) {
     const int ry = tid / RP, rx = 2 * (tid - ry * RP);
     int gx = (tx * T - H + rx) % a.nx; if (gx < 0) gx += a.nx;
     int gy = (ty * T - H + ry) % a.ny; if (gy < 0) gy += a.ny;
