@@ -48,40 +48,109 @@ __device__ __forceinline__ void store4(float* p, f4 v)
   else *reinterpret_cast<f4*>(p) = v;
 }
 
+// Sum over the 64 lanes of a FULL wave, every lane gets the total.  Data-parallel-primitive moves (v_mov_b32 dpp: a
+// register-to-register lane permutation at VALU latency) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32
+// — an LDS-crossbar round trip of ~100 cycles per level: the classic reduction quad_perm, quad_perm, row_half_mirror,
+// row_mirror (now every lane of a 16-lane row holds the row's sum), row_bcast15 into rows 1 and 3, row_bcast31 into
+// rows 2 and 3 (now row 3 holds the total), read lane 63.  Fixed order: deterministic.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_moved(double v)
+{
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = static_cast<int>(b & 0xffffffffull), hi = static_cast<int>(b >> 32);
+  // old = 0: lanes of rows outside ROW_MASK (and lanes whose source lane does not exist) receive +0.0
+  const unsigned int mlo = static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false));
+  const unsigned int mhi = static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false));
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(mhi) << 32) | mlo);
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v += dpp_moved<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v += dpp_moved<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v += dpp_moved<0x141, 0xF>(v);    // row_half_mirror
+  v += dpp_moved<0x140, 0xF>(v);    // row_mirror
+  v += dpp_moved<0x142, 0xA>(v);    // row_bcast15 -> rows 1, 3
+  v += dpp_moved<0x143, 0xC>(v);    // row_bcast31 -> rows 2, 3
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffull), 63));
+  const unsigned int hi = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(b >> 32), 63));
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// ---- several per-lane doubles at once (the per-step sums of a K-step kernel) ------------------------------------------------
+// N wave_sum()s cost N x 6 dependent butterfly stages.  Halving butterflies do the same work in log2(N) + the rest: gfx950's
+// v_permlane32_swap (lanes l <-> l ^ 32) and v_permlane16_swap (l <-> l ^ 16) hand the upper half of one value to the
+// lanes that keep the other, so each stage halves the number of values a lane carries; a third halving (N = 8) goes over
+// row_ror:8 (l <-> l ^ 8).  What is left is ONE value per lane, summed over the lanes of its class by DPP stages whose
+// every lane has a source (no `old` operand to initialise).  ~25 (N = 4) / ~40 (N = 8) instructions instead of ~45 per value.
+// All 64 lanes of the wave must be active.  Result: every lane holds the wave total of a[wave_sum_slot<N>(lane)].
+template <int N> __device__ __forceinline__ int wave_sum_slot(int lane)
+{
+  if constexpr (N == 4) return lane >> 4;                                            // row r: a[r]
+  else return ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + 4 * (lane >> 5);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_full(double v)                                   // CTRL reads an existing lane for every lane
+{
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = static_cast<unsigned int>(__builtin_amdgcn_mov_dpp(static_cast<int>(b & 0xffffffffull), CTRL, 0xF, 0xF, false));
+  const unsigned int hi = static_cast<unsigned int>(__builtin_amdgcn_mov_dpp(static_cast<int>(b >> 32), CTRL, 0xF, 0xF, false));
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// lanes < 32: a(l) + a(l + 32); lanes >= 32: b(l - 32) + b(l)
+__device__ __forceinline__ double halve_swap32(double a, double b)
+{
+  const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
+  const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned int>(ab), static_cast<unsigned int>(bb), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned int>(ab >> 32), static_cast<unsigned int>(bb >> 32), false, false);
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[0]) << 32) | lo[0]) +
+         __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[1]) << 32) | lo[1]);
+}
+
+// even rows (16 lanes each): a(l) + a(l + 16); odd rows: b(l - 16) + b(l)
+__device__ __forceinline__ double halve_swap16(double a, double b)
+{
+  const unsigned long long ab = __builtin_bit_cast(unsigned long long, a), bb = __builtin_bit_cast(unsigned long long, b);
+  const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned int>(ab), static_cast<unsigned int>(bb), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned int>(ab >> 32), static_cast<unsigned int>(bb >> 32), false, false);
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[0]) << 32) | lo[0]) +
+         __builtin_bit_cast(double, (static_cast<unsigned long long>(hi[1]) << 32) | lo[1]);
+}
+
+__device__ __forceinline__ double wave_sum_vec4(double a0, double a1, double a2, double a3)
+{
+  double v = halve_swap16(halve_swap32(a0, a2), halve_swap32(a1, a3));               // row r: a[r] over lanes l, l^16, l^32, l^48
+  v += dpp_full<0xB1>(v);           // quad_perm [1,0,3,2]
+  v += dpp_full<0x4E>(v);           // quad_perm [2,3,0,1]
+  v += dpp_full<0x141>(v);          // row_half_mirror
+  v += dpp_full<0x140>(v);          // row_mirror
   return v;
 }
 
-// N (a power of two, <= 8) per-lane values summed over the LANES (64, or the 32 low lanes of a half-filled wave) lanes
-// at once: at each of the first log2(N) levels a lane keeps half of its values and hands the other half to its
-// partner, so the N sums cost N-1 + (log2 LANES - log2 N) exchanges instead of N log2 LANES.  Afterwards lane L holds
-// the total of value L / (LANES / N) — lanes 0, LANES/N, 2 LANES/N, ... hold totals 0, 1, 2, ...  Fixed tree: deterministic.
-template <int N, int LANES = 64>
-__device__ __forceinline__ double wave_sum_multi(const double (&v)[N])
+__device__ __forceinline__ double wave_sum_vec8(const double (&a)[8])
 {
-  static_assert((N == 1 || N == 2 || N == 4 || N == 8) && (LANES == 64 || LANES == 32), "power of two up to 8; whole or half wave");
-  const int lane = threadIdx.x & 63;
-  double cur[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) cur[i] = v[i];
-  int n = N, off = LANES / 2;
-#pragma unroll
-  for (; n > 1; n >>= 1, off >>= 1) {
-    const bool upper = (lane & off) != 0;
-#pragma unroll
-    for (int i = 0; i < n / 2; ++i) {
-      const double mine = upper ? cur[i + n / 2] : cur[i];
-      const double theirs = upper ? cur[i] : cur[i + n / 2];
-      cur[i] = mine + __shfl_xor(theirs, off, 64);
-    }
-  }
-  double r = cur[0];
-#pragma unroll
-  for (; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
-  return r;
+  const double c0 = halve_swap16(halve_swap32(a[0], a[4]), halve_swap32(a[2], a[6]));   // row r: a[2 (r & 1) + 4 (r >> 1)]
+  const double c1 = halve_swap16(halve_swap32(a[1], a[5]), halve_swap32(a[3], a[7]));   //        a[1 + ...]
+  const bool upper = (threadIdx.x & 8) != 0;                                             // lanes 8-15 of a row keep c1
+  const double keep = upper ? c1 : c0, send = upper ? c0 : c1;
+  double v = keep + dpp_full<0x128>(send);                                               // row_ror:8 = lane l ^ 8
+  v += dpp_full<0xB1>(v);
+  v += dpp_full<0x4E>(v);
+  v += dpp_full<0x141>(v);          // row_half_mirror stays inside the eight lanes
+  return v;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release + acquire fence on ALL memory, i.e. an
+// s_waitcnt vmcnt(0) first: placed after a kernel's last global stores (the reductions at the end of every step kernel)
+// it keeps the whole block — its LDS, its wave slots — waiting a store round trip (1-2 k cycles) for nothing: the
+// stores complete on their own after the waves have ended.  Here: lgkmcnt(0) (this wave's LDS operations), then s_barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+  __builtin_amdgcn_s_waitcnt(0xC07F);          // vmcnt(63) expcnt(7) lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
 }
 
 // Deterministic block sum (fixed tree): every thread gets the total.
@@ -89,9 +158,9 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 d
 {
   v = wave_sum(v);
   const int wave = threadIdx.x >> 6;
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) lds[wave] = v;
-  __syncthreads();
+  lds_barrier();
   double t = lds[0];
 #pragma unroll
   for (int w = 1; w < kBlock / 64; ++w) t += lds[w];

@@ -273,12 +273,16 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
   }
 
   // per-step sums over the owned cells of this tile
-#pragma unroll
-  for (int q = 0; q < K; ++q) {
-    const double w = wave_sum(acc[q]);
-    if ((tid & 63) == 0) red[q * kWaves + (tid >> 6)] = w;
+  if constexpr (K == 1) {
+    const double w = wave_sum(acc[0]);
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+  } else {
+    static_assert(K <= 4, "wave_sum_vec4 carries four steps");
+    const double w = wave_sum_vec4(acc[0], acc[1], K > 2 ? acc[2] : 0.0, K > 3 ? acc[K > 3 ? 3 : 0] : 0.0);
+    const int q = wave_sum_slot<4>(tid & 63);
+    if ((tid & 15) == 0 && q < K) red[q * kWaves + (tid >> 6)] = w;
   }
-  __syncthreads();
+  lds_barrier();                 // LDS only: the block does not wait for its own global stores to complete
   if (tid < ksteps) {
     double t = 0.0;
     for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];

@@ -263,10 +263,12 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel(const StepArgs a)
     if (r < n1 + n2) acc += step_quad<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
   }
   acc = block_sum(acc, red);
+  // boundary launch of a peer-to-peer run: the outgoing halo rows were stored straight into the neighbours' windows;
+  // a full barrier drains every wave's stores (block_sum's barriers order LDS only), then one lane writes the XCD's L2
+  // back towards the peers
+  if (a.release_sends) __syncthreads();
   if (threadIdx.x == 0) {
     a.partials_out[wblock] = acc;
-    // boundary launch of a peer-to-peer run: the outgoing halo rows were stored straight into the neighbours' windows;
-    // block_sum's barriers have drained every wave's stores, this writes the XCD's L2 back towards the peers
     if (a.release_sends) __atomic_thread_fence(__ATOMIC_RELEASE);
   }
 }
@@ -287,9 +289,10 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel_narrow(const StepArgs 
     if (r < n1 + n2) acc += step_cell<NT>(a, r < n1 ? a.quad_begin + r : a.quad_begin2 + (r - n1));
   }
   acc = block_sum(acc, red);
+  if (a.release_sends) __syncthreads();                                  // see lbm_step_kernel
   if (threadIdx.x == 0) {
     a.partials_out[wblock] = acc;
-    if (a.release_sends) __atomic_thread_fence(__ATOMIC_RELEASE);      // see lbm_step_kernel
+    if (a.release_sends) __atomic_thread_fence(__ATOMIC_RELEASE);
   }
 }
 

@@ -29,6 +29,18 @@ namespace {
 // (both even); the block has R*R/2 lanes (the load phase: one aligned x-pair per lane).
 constexpr int kMaxTileSteps = 8;
 
+// Diagnostic builds only (scripts/build_variant.sh tile_stamps -DLBM_TILE_STAMPS=1, scripts/tile_stamps.py): shader-clock
+// stamps of block 1, lane 0 at the phase boundaries of a launch.  No stamp executes in the product build.
+#ifndef LBM_TILE_STAMPS
+#define LBM_TILE_STAMPS 0
+#endif
+#if LBM_TILE_STAMPS
+__device__ unsigned long long g_tile_stamps[16];
+#define LBM_STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_tile_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LBM_STAMP(i) do { } while (0)
+#endif
+
 template <int T, int H>
 struct TileGeom {
   static constexpr int R = T + 2 * H;
@@ -39,6 +51,7 @@ struct TileGeom {
   // shorter chains of the early sub-steps save)
   static constexpr int lanes = RP * R;
   static constexpr int waves = (lanes + 63) / 64;
+  static constexpr int block = 64 * waves;          // launched size: whole waves (288 -> 320), so that the wave-level sums see 64 active lanes
   static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * cells + sizeof(double) * H * waves + cells;   // + flag bytes
   static_assert(lanes <= 1024 && H <= kMaxTileSteps && T % 2 == 0 && H % 2 == 0, "unsupported tile geometry");
 };
@@ -63,10 +76,10 @@ struct TileArgs {
 };
 
 template <int T, int H, bool FULL, bool FAST>   // FULL: this launch does exactly H steps (region sizes are compile-time constants); FAST: float sum|u| terms
-__global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const TileArgs a)
+__global__ void __launch_bounds__((TileGeom<T, H>::block)) lbm_tile_kernel(const TileArgs a)
 {
   using G = TileGeom<T, H>;
-  constexpr int R = G::R, RP = G::RP, kCells = G::cells, kLanes = G::lanes, kWaves = G::waves;
+  constexpr int R = G::R, RP = G::RP, kCells = G::cells, kLanes = G::lanes, kWaves = G::waves, kBlock = G::block;
   extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][9][R*R] floats, reduction scratch, flag bytes
   double* red = reinterpret_cast<double*>(lds + 2 * 9 * kCells);    // [H][kWaves]
   uint8_t* cell_flags = reinterpret_cast<uint8_t*>(red + H * kWaves);   // per region cell: bit 0 obstacle, 1 owned, 2 on row ny-2
@@ -76,7 +89,7 @@ __global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const
     // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
     for (int v = 0; v < a.n_prev_vecs; ++v) {
       double s = 0.0;
-      for (int i = tid; i < a.n_prev; i += kLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
+      for (int i = tid; i < a.n_prev; i += kBlock) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
       s = wave_sum(s);
       __syncthreads();
       if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -92,6 +105,7 @@ __global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const
     return;
   }
 
+  LBM_STAMP(0);
   const int tile = blockIdx.x - 1;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   // does the region of this tile meet row ny-2 at all ?  (block-uniform; the others skip accelerate_flow)
@@ -117,6 +131,7 @@ __global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const
     *reinterpret_cast<uint16_t*>(cell_flags + c) = static_cast<uint16_t>(((mbits & 1u) | common) | ((((mbits >> 1) & 1u) | common) << 8));
   }
   __syncthreads();
+  LBM_STAMP(1);
 
   double acc[H];
 #pragma unroll
@@ -198,6 +213,7 @@ __global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const
       }
     }
     if (S < k_total) __syncthreads();
+    LBM_STAMP(1 + S);
   };
   if (1 <= k_total) substep(std::integral_constant<int, 1>{});
   if (2 <= k_total) substep(std::integral_constant<int, 2>{});
@@ -211,25 +227,23 @@ __global__ void __launch_bounds__((TileGeom<T, H>::lanes)) lbm_tile_kernel(const
   }
   static_assert(H == 4 || H == 8, "sub-steps are unrolled for H = 4 and 8");
 
-  // per-step sums over the owned cells of this tile: wave trees, then one lane per step over the waves
+  // per-step sums over the owned cells of this tile: one halving butterfly per wave (common.h), then one lane per step
+  // over the waves
   const int ntiles = gridDim.x - 1;
-  if ((tid | 63) < kLanes) {                     // wave-uniform: all 64 lanes of this wave exist
-    // all H sums of the wave in one butterfly: lane i * 64/H ends up with the total of step i
-    const double w = wave_sum_multi<H>(acc);
-    constexpr int kStride = 64 / H;
-    if ((tid & (kStride - 1)) == 0) red[((tid & 63) / kStride) * kWaves + (tid >> 6)] = w;
-  } else {                                       // the block's last wave is half full (288-lane geometries): the same on its 32 lanes
-    static_assert(kLanes % 64 == 0 || kLanes % 64 == 32, "whole or half last wave");
-    const double w = wave_sum_multi<H, 32>(acc);
-    constexpr int kStride = 32 / H;
-    if ((tid & (kStride - 1)) == 0) red[((tid & 31) / kStride) * kWaves + (tid >> 6)] = w;
+  if constexpr (H == 8) {
+    const double w = wave_sum_vec8(acc);
+    if ((tid & 7) == 0) red[wave_sum_slot<8>(tid & 63) * kWaves + (tid >> 6)] = w;
+  } else {
+    const double w = wave_sum_vec4(acc[0], acc[1], acc[2], acc[3]);
+    if ((tid & 15) == 0) red[wave_sum_slot<4>(tid & 63) * kWaves + (tid >> 6)] = w;
   }
-  __syncthreads();
+  lds_barrier();                 // LDS only: no wait for the tile's global stores
   if (tid < k_total) {
     double t = 0.0;
     for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
     a.partials_out[static_cast<size_t>(tid) * ntiles + tile] = t;
   }
+  LBM_STAMP(10);
 }
 
 }  // namespace

@@ -278,11 +278,11 @@ void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a, bool fast)
 {
   using G = TileGeom<T, H>;
   if (fast) {
-    if (a.ksteps == H) lbm_tile_kernel<T, H, true, true><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
-    else lbm_tile_kernel<T, H, false, true><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+    if (a.ksteps == H) lbm_tile_kernel<T, H, true, true><<<grid, dim3(G::block), G::lds_bytes, s>>>(a);
+    else lbm_tile_kernel<T, H, false, true><<<grid, dim3(G::block), G::lds_bytes, s>>>(a);
   } else {
-    if (a.ksteps == H) lbm_tile_kernel<T, H, true, false><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
-    else lbm_tile_kernel<T, H, false, false><<<grid, dim3(G::lanes), G::lds_bytes, s>>>(a);
+    if (a.ksteps == H) lbm_tile_kernel<T, H, true, false><<<grid, dim3(G::block), G::lds_bytes, s>>>(a);
+    else lbm_tile_kernel<T, H, false, false><<<grid, dim3(G::block), G::lds_bytes, s>>>(a);
   }
 }
 
@@ -1146,5 +1146,14 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 }
 
 }  // extern "C"
+
+#if LBM_TILE_STAMPS
+extern "C" int lbm_debug_tile_stamps(unsigned long long* out16)   // diagnostic builds only
+{
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 16));
+  return 0;
+}
+#endif
 
 #include "lbm_p2p_impl.h"   // peer-to-peer halo transport: drives the K-step launches above (include/lbm_d2q9_p2p.h)
