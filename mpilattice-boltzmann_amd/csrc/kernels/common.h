@@ -207,8 +207,37 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ float splat_as(float, float v) { return v; }
 __device__ __forceinline__ f2 splat_as(f2, float v) { return f2{v, v}; }
-__device__ __forceinline__ float recip_exact(float x) { return 1.0f / x; }                  // correctly rounded division (:561)
-__device__ __forceinline__ f2 recip_exact(f2 x) { f2 r; r.x = 1.0f / x.x; r.y = 1.0f / x.y; return r; }
+// 1.0f / x, correctly rounded (:561).  hipcc's division is twelve instructions (two div_scale, rcp, six fma, div_fmas,
+// div_fixup).  v_rcp_f32 and ONE Newton step give the same bits whenever the magnitude of their result is at least
+// 2^-126 (i.e. the result is a normal number; a NaN fails the comparison): checked against the division on all 2^32 bit
+// patterns on gfx950 (scripts/experiments/recip_exhaustive.hip) — so the test is one compare on the result, and a wave
+// that holds anything else (x zero, denormal, above 2^126, infinite or NaN) takes the division.
+#ifndef LBM_RECIP_DIVISION
+#define LBM_RECIP_DIVISION 0          // 1: timing / cross-check builds that always divide
+#endif
+__device__ __forceinline__ float recip_newton(float x)
+{
+  const float r = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float recip_exact(float x)
+{
+  if (LBM_RECIP_DIVISION) return 1.0f / x;
+  const float q = recip_newton(x);
+  if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(q) >= 0x1p-126f) == __builtin_amdgcn_read_exec()) return q;
+  return 1.0f / x;
+}
+__device__ __forceinline__ f2 recip_exact(f2 x)
+{
+  f2 r;
+  if (LBM_RECIP_DIVISION) { r.x = 1.0f / x.x; r.y = 1.0f / x.y; return r; }
+  r.x = recip_newton(x.x); r.y = recip_newton(x.y);
+  const unsigned long long ok = __builtin_amdgcn_ballot_w64(__builtin_fabsf(r.x) >= 0x1p-126f) & __builtin_amdgcn_ballot_w64(__builtin_fabsf(r.y) >= 0x1p-126f);
+  if (ok == __builtin_amdgcn_read_exec()) return r;
+  r.x = 1.0f / x.x; r.y = 1.0f / x.y;
+  return r;
+}
 
 template <typename T>
 __device__ __forceinline__ void relax_core(const T (&t)[9], float omega, T (&o)[9], T& msq_out, T& rinv_out)

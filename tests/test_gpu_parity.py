@@ -157,6 +157,63 @@ def test_set_cells_random_state(lbm, oracle, kernel_form):
     part.close()
 
 
+def test_short_reciprocal_equals_the_division_on_every_float(tmp_path):
+    """relax_core's 1.0f / density (d2q9-bgk.c:561) is v_rcp_f32 + one Newton step wherever the result is a normal number and
+    the compiler's IEEE division elsewhere (kernels/common.h recip_exact).  That the two agree is not an argument but a
+    count: all 2^32 bit patterns, on this GPU, every run of the suite (about a second)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "experiments", "recip_exhaustive.hip")
+    exe = str(tmp_path / "recip_exhaustive")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", src, "-o", exe], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of them differ" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("form", ["vector", "tile", "multi"])
+@pytest.mark.parametrize("steps", [1, 3])
+def test_cells_outside_the_short_reciprocal(lbm, oracle, monkeypatch, form, steps):
+    """Densities the short reciprocal does not cover — zero, denormal, above 2^126 — send their wave down the division:
+    a 3x3 block of populations 2^123 (density 9 * 2^123 > 2^126: reciprocal denormal, momentum exactly zero, so the centre stays finite), a block of
+    zeros (1/0) and a block of denormals (1/x overflows).  Bits equal the oracle's wherever it holds a number; where it
+    holds a NaN the device holds one too."""
+    if form == "vector":
+        monkeypatch.setenv("LBM_TUNE_NARROW_MAX", "0")
+    if form != "tile":
+        monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    if form != "multi":
+        monkeypatch.setenv("LBM_TUNE_MULTI_K", "0")
+    nx, ny = 64, 32
+    rng = np.random.default_rng(5)
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.02, 1.6)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, 3, False)
+    cells0 = (rng.random((ny, nx, 9), dtype=np.float32) * 0.02 + 0.004).astype(np.float32)
+    cells0[10:13, 10:13, :] = np.float32(2.0 ** 123)
+    cells0[19:22, 39:42, :] = np.float32(0.0)
+    cells0[25:28, 20:23, :] = np.float32(1e-40)
+    obst[9:14, 9:14] = 0
+    obst[18:23, 38:43] = 0
+    obst[24:29, 19:24] = 0
+    part = lbm.Partition(p, lbm.count_free_cells(obst), obst)
+    part.set_cells(cells0)
+    with np.errstate(all="ignore"):
+        part.run(steps)
+        got = part.get_cells()
+        ref_cells, _ = oracle.run_from(p, obst, cells0, steps)
+    if form == "multi":
+        assert "lbm_multi_kernel" in part.describe()["kernel"]
+    if form == "tile":
+        assert "lbm_tile_kernel" in part.describe()["kernel"]
+    nan_ref, nan_got = np.isnan(ref_cells), np.isnan(got)
+    assert nan_ref.any() and not nan_ref.all()
+    assert np.array_equal(nan_ref, nan_got)
+    assert np.array_equal(bits(got)[~nan_got], bits(ref_cells)[~nan_ref])
+    if steps == 1:          # the centre of the 2^123 block went through the division with a denormal reciprocal and stayed finite
+        assert np.all(np.isfinite(got[11, 11])) and np.all(np.abs(got[11, 11]) > 1e35)
+    part.close()
+
+
 @pytest.mark.parametrize("nx,ny", [(4, 3), (8, 3), (4, 64), (2048, 3), (12, 7), (36, 5), (1028, 6)])
 def test_odd_shapes(lbm, oracle, kernel_form, nx, ny):
     """nx only needs to be a multiple of 4 here (the reference silently needs 8, d2q9-bgk.c:453,520);
