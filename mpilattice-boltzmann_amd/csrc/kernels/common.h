@@ -145,12 +145,14 @@ __device__ __forceinline__ double wave_sum_vec8(const double (&a)[8])
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release + acquire fence on ALL memory, i.e. an
 // s_waitcnt vmcnt(0) first: placed after a kernel's last global stores (the reductions at the end of every step kernel)
-// it keeps the whole block — its LDS, its wave slots — waiting a store round trip (1-2 k cycles) for nothing: the
-// stores complete on their own after the waves have ended.  Here: lgkmcnt(0) (this wave's LDS operations), then s_barrier.
+// it keeps the whole block — its LDS, its wave slots — waiting a store round trip (1-2 k cycles) for nothing, and placed
+// between the sub-steps of lbm_multi_kernel it would wait for the NEXT tile's prefetched loads.  Here the fences name the
+// LDS address space: s_waitcnt lgkmcnt(0), s_barrier, and the compiler keeps LDS accesses on their side of it.
 __device__ __forceinline__ void lds_barrier()
 {
-  __builtin_amdgcn_s_waitcnt(0xC07F);          // vmcnt(63) expcnt(7) lgkmcnt(0)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Deterministic block sum (fixed tree): every thread gets the total.

@@ -31,6 +31,12 @@ constexpr int kMTXNarrow = 32;
 // side: columns grow twice as fast so that every region starts on an even x and a lane can own an
 // x-PAIR of cells (8-byte accesses; the two cells' arithmetic is packed by the compiler into
 // v_pk_*_f32, which halves the instruction count - the one-cell form of this kernel was VALU-bound).
+#if LBM_TILE_STAMPS      // diagnostic builds (tile.h, scripts/tile_stamps.py): stamps of one block in the middle of the launch, lane 0
+#define LBM_MSTAMP(i) do { if (blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) g_tile_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LBM_MSTAMP(i) do { } while (0)
+#endif
+
 template <int K, int TX = kMTX>
 struct MultiGeom {
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
@@ -100,6 +106,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
     return;
   }
 
+  LBM_MSTAMP(0);
   int b = blockIdx.x - 1;
   if (a.xcd_remap) {
     // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD one contiguous eighth of
@@ -207,8 +214,10 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       }
     }
   }
+  LBM_MSTAMP(1);
   if constexpr (K >= 2) {
     __syncthreads();
+    LBM_MSTAMP(2);
     // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller.
     // In place without holding a whole region in registers: sub-step j writes its row r where the
     // frame it read kept row r-1 (the frame creeps down one storage row per sub-step), and a region
@@ -266,6 +275,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
         }
       }
       if (!last) __syncthreads();
+      LBM_MSTAMP(1 + j);
     };
     // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
 #pragma unroll
@@ -288,6 +298,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
     for (int w = 0; w < kWaves; ++w) t += red[tid * kWaves + w];
     a.partials_out[static_cast<size_t>(tid) * a.ntiles_total + tile] = t;
   }
+  LBM_MSTAMP(2 + K);
 }
 
 }  // namespace

@@ -41,13 +41,19 @@ for _ in range(3):
 st = (C.c_ulonglong * 16)()
 assert lib.lbm_debug_tile_stamps(st) == 0
 t = [int(v) for v in st]
-labels = ["load"] + [f"sub-step {i}" for i in range(1, 9)] + ["epilogue"]
+if "multi" in name.value.decode():      # lbm_multi_kernel<K>: a block in the middle of the launch, its CU shared with two others
+    labels = ["sub-step 1 (global loads, relax, LDS writes)", "barrier"] + [f"sub-step {i} (in LDS)" for i in range(2, 9)]
+    k = int(name.value.decode().split("<")[1].split(",")[0].split(">")[0])
+    labels = labels[:1 + k] + ["epilogue (sums)"]
+    labels[k] = f"sub-step {k} (LDS -> global stores)" if k > 1 else labels[k]
+else:
+    labels = ["load"] + [f"sub-step {i}" for i in range(1, 9)] + ["epilogue"]
 print(name.value.decode(), a.grid)
 prev = t[0]
 for i, lab in enumerate(labels, start=1):
     if t[i] <= prev:
         continue
-    print(f"  {lab:12s} {t[i] - prev:7d} cycles")
+    print(f"  {lab:46s} {t[i] - prev:7d} cycles")
     prev = t[i]
-print(f"  total        {prev - t[0]:7d} cycles (shader clock; 100 MHz-independent)")
+print(f"  {'total':46s} {prev - t[0]:7d} cycles (shader clock)")
 lib.lbm_destroy(ctx)
