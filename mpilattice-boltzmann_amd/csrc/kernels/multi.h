@@ -78,7 +78,7 @@ template <int K, bool FAST, int TX>   // FAST: float sum|u| terms (LBM_FLAG_FAST
 __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, TX>;
-  constexpr int EX = G::EX, EY = G::EY, W = G::W, kCells = G::cells, kWaves = kMLanes / 64;
+  constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kWaves = kMLanes / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
   // per x-pair of the frame, written by sub-step 1 and read by the in-LDS sub-steps (which then need no
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       acc[0] += finish_pair<FAST>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out);
       if (ksteps > 1) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + fy * W + fx) = out[k];
+        for (int k = 0; k < 9; ++k) { lds[k * kCells + fy * W + (fx >> 1)] = out[k].x; lds[k * kCells + fy * W + (fx >> 1) + WH] = out[k].y; }
         pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u);
       } else if (owned) {
 #pragma unroll
@@ -243,17 +243,22 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           const int cf = fy * W + fx;                                    // frame position; stored rd (read) / wr (written) lower
           const uint32_t fl = pair_flags[cf >> 1];
           const bool lane_on = in_region && (fl & 16u);
-          const int c = cf - rd;
+          // frame rows are stored de-interleaved — the even-x cells of a row, then its odd-x cells (WH = W/2 each) — so
+          // that a wave's lanes read consecutive dwords whichever neighbour they pull: a pair (x, x+1), x even, is
+          // E[i], O[i] (i = x/2); its west pulls are O[i-1], E[i]; its east pulls O[i], E[i+1].  Every access one
+          // ds_read2_b32 / ds_write2_b32 without bank conflicts (interleaved, the x -+ 1 pulls were dword pairs at odd
+          // addresses with lane stride 2: two-way conflicts, 76 % of the LDS-active cycles).
+          const int c = fy * W + (fx >> 1) - rd;
           f2 p[9];
-          p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + c);
-          p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + c - W);
-          p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + c + W);
-          p[1] = f2{lds[1 * kCells + c - 1], lds[1 * kCells + c]};
-          p[5] = f2{lds[5 * kCells + c - W - 1], lds[5 * kCells + c - W]};
-          p[8] = f2{lds[8 * kCells + c + W - 1], lds[8 * kCells + c + W]};
-          p[3] = f2{lds[3 * kCells + c + 1], lds[3 * kCells + c + 2]};
-          p[6] = f2{lds[6 * kCells + c - W + 1], lds[6 * kCells + c - W + 2]};
-          p[7] = f2{lds[7 * kCells + c + W + 1], lds[7 * kCells + c + W + 2]};
+          p[0] = f2{lds[0 * kCells + c], lds[0 * kCells + c + WH]};
+          p[2] = f2{lds[2 * kCells + c - W], lds[2 * kCells + c - W + WH]};
+          p[4] = f2{lds[4 * kCells + c + W], lds[4 * kCells + c + W + WH]};
+          p[1] = f2{lds[1 * kCells + c + WH - 1], lds[1 * kCells + c]};
+          p[5] = f2{lds[5 * kCells + c - W + WH - 1], lds[5 * kCells + c - W]};
+          p[8] = f2{lds[8 * kCells + c + W + WH - 1], lds[8 * kCells + c + W]};
+          p[3] = f2{lds[3 * kCells + c + WH], lds[3 * kCells + c + 1]};
+          p[6] = f2{lds[6 * kCells + c - W + WH], lds[6 * kCells + c - W + 1]};
+          p[7] = f2{lds[7 * kCells + c + W + WH], lds[7 * kCells + c + W + 1]};
           const bool owned = lane_on && (fl & 4u);
           const double term = finish_pair<FAST>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
                                           owned ? (fl & 3u) : 3u, outs);
@@ -261,13 +266,13 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;
           // an owned pair lies inside the grid: its cell index needs no periodic wrap
-          slot = !lane_on ? -1 : last ? (owned ? (sy0 + fy - EY) * nx + x0 + fx - EX : -1) : cf - wr;
+          slot = !lane_on ? -1 : last ? (owned ? (sy0 + fy - EY) * nx + x0 + fx - EX : -1) : fy * W + (fx >> 1) - wr;
         }
         if (!last) {
           __syncthreads();                     // every lane of the pass has read its neighbours
           if (slot >= 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) *reinterpret_cast<f2*>(lds + k * kCells + slot) = outs[k];
+            for (int k = 0; k < 9; ++k) { lds[k * kCells + slot] = outs[k].x; lds[k * kCells + slot + WH] = outs[k].y; }
           }
         } else if (slot >= 0) {
 #pragma unroll

@@ -37,9 +37,14 @@ free_cells = int(obst.size - obst.sum())
 cp = _capi.CParams(p.nx, p.ny, p.max_iters, p.reynolds_dim, p.density, p.accel, p.omega)
 
 ctxs = []
-for spec in a.libs:                       # "path.so" or "path.so:FLAGS" (lbm_create flags for that entry, e.g. 64 = fast av_vels)
-    path, _, fl = spec.partition(":")
+for n_spec, spec in enumerate(a.libs):    # "path.so", "path.so:FLAGS" (lbm_create flags, e.g. 64 = fast av_vels) or "path.so:FLAGS:KEY=VAL,KEY=VAL"
+    parts = spec.split(":")               # (environment for that entry's lbm_create only; empty FLAGS = --flags)
+    path, fl = parts[0], parts[1] if len(parts) > 1 else ""
     flags = int(fl) if fl else a.flags
+    own_env = dict(kv.split("=") for kv in parts[2].split(",")) if len(parts) > 2 and parts[2] else {}
+    saved = {k: os.environ.get(k) for k in own_env}
+    os.environ.update(own_env)
+    spec = f"{n_spec}:{spec}"             # the same library may appear more than once (allocation order matters by ~3 %)
     lib = C.CDLL(os.path.abspath(path))
     for name in ("lbm_create", "lbm_run", "lbm_last_run_kernel_ms", "lbm_destroy", "lbm_last_error"):
         fn = getattr(lib, name)
@@ -48,6 +53,11 @@ for spec in a.libs:                       # "path.so" or "path.so:FLAGS" (lbm_cr
     if lib.lbm_create(C.byref(ctx), C.byref(cp), free_cells, obst.ctypes.data_as(C.POINTER(C.c_int)), 0, ny, 0, flags):
         raise SystemExit(f"{path}: {lib.lbm_last_error().decode()}")
     ctxs.append((spec, lib, ctx))
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 av = (C.c_float * a.steps)()
 res = {path: [] for path, _, _ in ctxs}
@@ -66,5 +76,5 @@ ref = digest[ctxs[0][0]]
 for path, lib, ctx in ctxs:
     v = res[path]
     same = "av==first" if digest[path] == ref else "av DIFFERS from first"
-    print(f"{os.path.basename(path):40s} min {min(v):8.1f}  med {statistics.median(v):8.1f}  max {max(v):8.1f} us/step   {same}", flush=True)
+    print(f"{path.split(':', 1)[0]:>2s} {os.path.basename(path.split(':', 1)[1]):50s} min {min(v):8.1f}  med {statistics.median(v):8.1f}  max {max(v):8.1f} us/step   {same}", flush=True)
     lib.lbm_destroy(ctx)
