@@ -515,6 +515,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     HIP_TRY_C(hipMemsetAsync(c->grid_alloc[g], 0, sizeof(float) * c->grid_floats, c->stream));
     c->grid[g] = c->grid_alloc[g] + 64;
   }
+  if (tune_env("LBM_DEBUG_ADDR", 0))      // placement experiments (scripts/experiments/alloc_order.py)
+    std::fprintf(stderr, "lbm_create: grids at %p %p (%zu bytes each, plane stride %zu floats)\n", static_cast<void*>(c->grid_alloc[0]),
+                 static_cast<void*>(c->grid_alloc[1]), sizeof(float) * c->grid_floats, c->ps);
   // obstacle bitfield
   const size_t mwords = (c->ncells_storage + 31) / 32 + 4;
   std::vector<uint32_t> bits(mwords, 0u);
