@@ -46,9 +46,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="8192x8192", help="NXxNY of the synthetic deck (default: the BASELINE config)")
-    ap.add_argument("--reps", type=int, default=5,
+    ap.add_argument("--reps", type=int, default=0,
                     help="the timed region (EXACTLY --steps steps between two barriers) is repeated this many times and the "
-                         "MEDIAN is reported: a single short region carries the first launches' ramp")
+                         "MEDIAN is reported: a single short region carries the first launches' ramp.  Default: 5, or 9 when "
+                         "--steps <= 50 (a 7 ms region is still ramping through its first three repetitions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ring", action="store_true",
                     help="N=1 only: run the row-partitioned code path on a 1-rank ring (the rank exchanges with itself)")
@@ -63,7 +64,10 @@ def parse_args(argv=None):
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="self-launch: seconds before a set of rank processes is given up")
     ap.add_argument("--dry-launch", action="store_true",
                     help="self-launch test: the rank processes only rendezvous (gloo), report their ranks and exit; no GPU is touched")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.reps <= 0:
+        args.reps = 9 if args.steps <= 50 else 5
+    return args
 
 
 def host_cores() -> int:
