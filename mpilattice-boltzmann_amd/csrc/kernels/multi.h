@@ -71,6 +71,19 @@ struct MultiArgs {
   int* counter;
 };
 
+// A pair (x, x+1), x even, of population k into row `row` (a dword index) of an LDS frame of row stride W: interleaved
+// for the populations pulled without an x shift, odd-x cells first then even-x cells for the others (see the reads).
+template <int W>
+__device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx, f2 v)
+{
+  if (k == 0 || k == 2 || k == 4) {
+    *reinterpret_cast<f2*>(plane + row + fx) = v;
+  } else {
+    plane[row + (fx >> 1)] = v.y;
+    plane[row + (fx >> 1) + W / 2] = v.x;
+  }
+}
+
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
@@ -206,7 +219,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
       acc[0] += finish_pair<FAST>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out);
       if (ksteps > 1) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { lds[k * kCells + fy * W + (fx >> 1)] = out[k].x; lds[k * kCells + fy * W + (fx >> 1) + WH] = out[k].y; }
+        for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, fy * W, fx, out[k]);
         pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u);
       } else if (owned) {
 #pragma unroll
@@ -243,23 +256,24 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           const int cf = fy * W + fx;                                    // frame position; stored rd (read) / wr (written) lower
           const uint32_t fl = pair_flags[cf >> 1];
           const bool lane_on = in_region && (fl & 16u);
-          // frame rows are stored de-interleaved — the even-x cells of a row, then its odd-x cells (WH = W/2 each) — so
-          // that a wave's lanes read consecutive dwords whichever neighbour they pull: a pair (x, x+1), x even, is
-          // E[i], O[i] (i = x/2); its west pulls are O[i-1], E[i]; its east pulls O[i], E[i+1].  Every access one
-          // ds_read2_b32 / ds_write2_b32 over consecutive dwords (interleaved, the x -+ 1 pulls were dword pairs at odd
-          // addresses with lane stride 2).  The bank-conflict counter stays where it was — a wave spans two region rows
-          // whose banks overlap — and K = 3 times the same; K = 4 gains 5 %.
-          const int c = fy * W + (fx >> 1) - rd;
+          // Frame layout, per population: the three that are pulled without an x shift (0, 2, 4) keep their rows
+          // interleaved — a pair is one aligned ds_read_b64.  The six that are pulled from x -+ 1 have their rows stored
+          // DE-INTERLEAVED, odd-x cells first: a row is O[0..WH), E[0..WH) (WH = W/2).  For a pair (x, x+1), x = 2i, the
+          // west pulls are O[i-1], E[i] and the east pulls O[i], E[i+1]: one ds_read2_b32 each, ascending addresses in
+          // lane order (no register swap), lanes on consecutive dwords (interleaved, they were dword pairs at odd
+          // addresses with lane stride 2, two-way bank conflicts in both passes of the instruction).
+          const int ci = cf - rd;                                        // interleaved planes: cell (fx, fy)
+          const int cs = fy * W + (fx >> 1) - rd;                        // split planes: O[i] of row fy; E[i] is WH further
           f2 p[9];
-          p[0] = f2{lds[0 * kCells + c], lds[0 * kCells + c + WH]};
-          p[2] = f2{lds[2 * kCells + c - W], lds[2 * kCells + c - W + WH]};
-          p[4] = f2{lds[4 * kCells + c + W], lds[4 * kCells + c + W + WH]};
-          p[1] = f2{lds[1 * kCells + c + WH - 1], lds[1 * kCells + c]};
-          p[5] = f2{lds[5 * kCells + c - W + WH - 1], lds[5 * kCells + c - W]};
-          p[8] = f2{lds[8 * kCells + c + W + WH - 1], lds[8 * kCells + c + W]};
-          p[3] = f2{lds[3 * kCells + c + WH], lds[3 * kCells + c + 1]};
-          p[6] = f2{lds[6 * kCells + c - W + WH], lds[6 * kCells + c - W + 1]};
-          p[7] = f2{lds[7 * kCells + c + W + WH], lds[7 * kCells + c + W + 1]};
+          p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + ci);
+          p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + ci - W);
+          p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + ci + W);
+          p[1] = f2{lds[1 * kCells + cs - 1], lds[1 * kCells + cs + WH]};
+          p[5] = f2{lds[5 * kCells + cs - W - 1], lds[5 * kCells + cs - W + WH]};
+          p[8] = f2{lds[8 * kCells + cs + W - 1], lds[8 * kCells + cs + W + WH]};
+          p[3] = f2{lds[3 * kCells + cs], lds[3 * kCells + cs + WH + 1]};
+          p[6] = f2{lds[6 * kCells + cs - W], lds[6 * kCells + cs - W + WH + 1]};
+          p[7] = f2{lds[7 * kCells + cs + W], lds[7 * kCells + cs + W + WH + 1]};
           const bool owned = lane_on && (fl & 4u);
           const double term = finish_pair<FAST>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
                                           owned ? (fl & 3u) : 3u, outs);
@@ -267,13 +281,13 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(cons
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;
           // an owned pair lies inside the grid: its cell index needs no periodic wrap
-          slot = !lane_on ? -1 : last ? (owned ? (sy0 + fy - EY) * nx + x0 + fx - EX : -1) : fy * W + (fx >> 1) - wr;
+          slot = !lane_on ? -1 : last ? (owned ? (sy0 + fy - EY) * nx + x0 + fx - EX : -1) : fy * W - wr;   // in LDS: the row; fx is added below
         }
         if (!last) {
           __syncthreads();                     // every lane of the pass has read its neighbours
           if (slot >= 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { lds[k * kCells + slot] = outs[k].x; lds[k * kCells + slot + WH] = outs[k].y; }
+            for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, slot, fx, outs[k]);
           }
         } else if (slot >= 0) {
 #pragma unroll
