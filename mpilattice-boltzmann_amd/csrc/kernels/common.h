@@ -174,18 +174,18 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 d
 // fold's latency (a dependent load + two barriers) is off the critical path of the tiny grids.
 __device__ __forceinline__ void fold_previous(const StepArgs& a, double* red);
 
-// sqrt((double)x) for a float x (d2q9-bgk.c:667 promotes u_sq to double).  Same Newton sequence on
-// v_rsq_f64 that hipcc emits for sqrt(double), minus its 2^256 rescaling of arguments below 2^-767,
-// which a converted float never is: bit-identical results, a quarter fewer instructions.
+// sqrt((double)x) for a float x (d2q9-bgk.c:667 promotes u_sq to double), correctly rounded.  hipcc's sqrt(double) is
+// v_rsq_f64, one joint refinement of g ~ sqrt(x) and h ~ 1/(2 sqrt(x)), two Newton corrections of g and a rescaling of
+// arguments below 2^-767: 11 + 5 instructions.  A converted float is never that small, and for a 24-bit significand the
+// refinement is not needed: the raw estimates followed by two corrections already give the correctly rounded result for
+// EVERY non-negative float — 2 139 095 041 values enumerated on gfx950, scripts/experiments/sqrt_exhaustive.hip (one
+// correction after the refinement would do as well; one correction alone is wrong for half of them).  7 instructions.
 __device__ __forceinline__ double sqrt_of_float(float xf)
 {
   const double x = static_cast<double>(xf);
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
-  double h = y * 0.5;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
+  const double h = y * 0.5;
   double d = __builtin_fma(-g, g, x);
   g = __builtin_fma(d, h, g);
   d = __builtin_fma(-g, g, x);
