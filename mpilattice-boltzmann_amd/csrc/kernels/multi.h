@@ -22,7 +22,11 @@ namespace {
 // Rows outside the partition: `y_periodic` wraps (self-contained domain); otherwise the storage has
 // `ghost` extra rows below and above the owned rows, filled by the neighbours before the launch.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMTX = 64, kMTY = 16, kMLanes = 512, kMaxMultiSteps = 4;
+#ifndef LBM_MTY            // experiment builds: -DLBM_MTY=24 -DLBM_MLANES=768 (taller tiles, two blocks per CU)
+#define LBM_MTY 16
+#define LBM_MLANES 512
+#endif
+constexpr int kMTX = 64, kMTY = LBM_MTY, kMLanes = LBM_MLANES, kMaxMultiSteps = 4;
 // Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:
 // twice the tiles, each with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
 constexpr int kMTXNarrow = 32;

@@ -231,6 +231,14 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 template <int K, int TX>
 void launch_multi_kt(int blocks, hipStream_t s, const MultiArgs& a, bool fast)
 {
+  if constexpr (MultiGeom<K, TX>::lds_bytes > 65536) {       // experiment builds with taller tiles: frames above the default limit
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, true, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MultiGeom<K, TX>::lds_bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, false, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MultiGeom<K, TX>::lds_bytes));
+      raised = true;
+    }
+  }
   if (fast) lbm_multi_kernel<K, true, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
   else lbm_multi_kernel<K, false, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
 }
