@@ -26,6 +26,9 @@ namespace {
 #define LBM_MTY 16
 #define LBM_MLANES 512
 #endif
+#ifndef LBM_MWAVES         // waves per SIMD the K <= 3 kernels are compiled for (register budget 512 / LBM_MWAVES)
+#define LBM_MWAVES 6
+#endif
 constexpr int kMTX = 64, kMTY = LBM_MTY, kMLanes = LBM_MLANES, kMaxMultiSteps = 4;
 // Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:
 // twice the tiles, each with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
@@ -92,7 +95,7 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
 template <int K, bool FAST, int TX>   // FAST: float sum|u| terms (LBM_FLAG_FAST_AVVELS), see finish_pair; TX: tile width
-__global__ void __launch_bounds__(kMLanes, K <= 3 ? 6 : 4) lbm_multi_kernel(const MultiArgs a)
+__global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, TX>;
   constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kWaves = kMLanes / 64;
