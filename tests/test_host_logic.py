@@ -323,3 +323,16 @@ def test_bench_starts_its_own_rank_processes(n):
     assert sorted(d["rank"] for d in out["ranks"]) == list(range(n)) and all(d["world"] == n for d in out["ranks"])
     assert len({d["pid"] for d in out["ranks"]}) == n and os.getpid() not in {d["pid"] for d in out["ranks"]}
     assert out["launch_attempts"][0]["returncode"] == 0
+
+
+@pytest.mark.parametrize("name", ["recip_exhaustive.hip", "sqrt_exhaustive.hip", "grid_barrier.hip"])
+def test_enumeration_programs_compile_for_gfx950(tmp_path, name):
+    """The exhaustive checks behind the short reciprocal and the short double sqrt run on the GPU box (test_gpu_parity.py
+    compiles them there); here only that they cross-compile, so a typo cannot turn those GPU tests red."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "scripts", "experiments", name)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", src, "-o", str(tmp_path / "a.out")],
+                   check=True, capture_output=True, timeout=600)
