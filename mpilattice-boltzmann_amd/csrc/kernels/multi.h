@@ -140,6 +140,8 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
   const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
   const int nx = a.nx;
   const int rows_storage = a.rows_owned + 2 * a.ghost;
+  const int tile_row_base = sy0 * nx;               // block-uniform: a scalar multiply
+  const int grid_cells = rows_storage * nx;
   constexpr int ksteps = K;
   double acc[K];
 #pragma unroll
@@ -174,27 +176,31 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
       const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
       int gx = x0 + fx - EX;
       int sr = sy0 + fy - EY;
-      int ys = sr - 1, yn = sr + 1;
+      // One multiply per pair, and a 24-bit one (v_mul_lo_u32 and v_mad_u64_u32 issue at quarter rate: the three
+      // products sr * nx, ys * nx, yn * nx were 48 cycles of a pass): the tile's first row is a scalar product, the row
+      // inside the frame a small factor (nx < 2^23 is part of the kernel's eligibility), the rows above and below and
+      // the periodic wraps are additions.
+      int cell = tile_row_base + __mul24(fy - EY, nx) + gx;
+      int d_south = -nx, d_north = nx;
       if (!inner) {
-        if (gx < 0) gx += nx; else if (gx >= nx) gx -= nx;                                // periodic (:527-529)
+        if (gx < 0) { gx += nx; cell += nx; } else if (gx >= nx) { gx -= nx; cell -= nx; }      // periodic (:527-529)
         // row partition whose rows the tile height does not divide: the last tile row sticks out past the
         // ghost rows; those cells lie outside every owned cell's dependency cone and are skipped
-        if (!a.y_periodic && yn >= rows_storage) {
+        if (!a.y_periodic && sr + 1 >= rows_storage) {
           if (ksteps > 1) pair_flags[(fy * W + fx) >> 1] = 0;
           continue;
         }
         if (a.y_periodic) {                                                               // periodic (:245-247)
-          if (sr < 0) sr += rows_storage; else if (sr >= rows_storage) sr -= rows_storage;
-          ys = (sr == 0) ? rows_storage - 1 : sr - 1;
-          yn = (sr + 1 >= rows_storage) ? 0 : sr + 1;
+          if (sr < 0) { sr += rows_storage; cell += grid_cells; } else if (sr >= rows_storage) { sr -= rows_storage; cell -= grid_cells; }
+          if (sr == 0) d_south = grid_cells - nx;
+          if (sr + 1 >= rows_storage) d_north = nx - grid_cells;
         }
       }
       // three 32-bit byte offsets per lane on block-uniform plane bases (scalar base + vector offset
       // addressing: no 64-bit address arithmetic in the vector unit; the x -+ 1 shifts live in the bases)
-      const int cell = sr * nx + gx;
       const uint32_t o_here = 4u * static_cast<uint32_t>(cell);
-      const uint32_t o_south = 4u * static_cast<uint32_t>(ys * nx + gx);
-      const uint32_t o_north = 4u * static_cast<uint32_t>(yn * nx + gx);
+      const uint32_t o_south = 4u * static_cast<uint32_t>(cell + d_south);
+      const uint32_t o_north = 4u * static_cast<uint32_t>(cell + d_north);
       f2 p[9];
       p[0] = at_byte<f2>(a.srck[0], o_here);                                                   // :530
       p[2] = at_byte<f2>(a.srck[2], o_south);                                         // :532
@@ -288,7 +294,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
           for (int m = 1; m < K; ++m)
             if (m == j - 1) acc[m] += term;
           // an owned pair lies inside the grid: its cell index needs no periodic wrap
-          slot = !lane_on ? -1 : last ? (owned ? (sy0 + fy - EY) * nx + x0 + fx - EX : -1) : fy * W - wr;   // in LDS: the row; fx is added below
+          slot = !lane_on ? -1 : last ? (owned ? tile_row_base + __mul24(fy - EY, nx) + x0 + fx - EX : -1) : fy * W - wr;   // in LDS: the row; fx is added below
         }
         if (!last) {
           __syncthreads();                     // every lane of the pass has read its neighbours

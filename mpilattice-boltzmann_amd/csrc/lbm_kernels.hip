@@ -380,7 +380,7 @@ static bool macro_eligible(const lbm_params* p, int rows, unsigned flags)
 {
   // the multi kernel addresses a plane with 32-bit byte offsets: < 2^30 storage cells
   const bool fits_u32 = static_cast<size_t>(p->nx) * (rows + 2 * kMaxMultiSteps) < (size_t(1) << 30);
-  return !(flags & LBM_FLAG_ONE_STEP) && rows >= 2 * kMTY && fits_u32 && (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX));
+  return !(flags & LBM_FLAG_ONE_STEP) && rows >= 2 * kMTY && fits_u32 && p->nx < (1 << 23) && (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX));
 }
 
 // K for partitions of at most `max_cells` cells.  Measured on a 1-rank ring with the packed exchange,
@@ -584,7 +584,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
-  } else if (!c->tile_kernel && self_periodic && fits_u32 &&
+  } else if (!c->tile_kernel && self_periodic && fits_u32 && p->nx < (1 << 23) &&      // (24-bit row multiplies in lbm_multi_kernel)
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
     // sticks out of the grid (periodic images: computed, not kept)
