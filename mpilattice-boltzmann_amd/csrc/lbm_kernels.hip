@@ -140,6 +140,7 @@ struct lbm_ctx {
   int multi_K = 0;           // > 0: bandwidth-bound grid advanced K steps per launch by lbm_multi_kernel<K>
   int multi_tiles_x = 0, multi_tiles = 0;
   int multi_tx = kMTX;       // tile width of lbm_multi_kernel: 64, or 32 for partitions of one round of blocks
+  bool multi_tail4 = true;   // lbm_run at K = 3: 4-step launches instead of a 1- or 2-step tail (LBM_TUNE_MULTI_TAIL4)
   bool tile_kernel = false;  // lbm_run advances several steps per launch with lbm_tile_kernel (small grids)
   int tile_T = 16, tile_H = 8;   // its geometry: owned tile edge, ghost ring = max steps per launch
   int tile_single_max = 0;       // sub-steps with regions of at most this many cells deal one cell per lane
@@ -273,7 +274,7 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
-  switch (std::min(ksteps, c->multi_K)) {
+  switch (ksteps) {                                            // <= multi_K, or 4 in the tail of a K = 3 run (lbm_run)
     case 1: launch_multi_k<1>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
     case 2: launch_multi_k<2>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
     case 3: launch_multi_k<3>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
@@ -593,6 +594,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     //   1024x1024 11.2 / 8.3 / 8.5 (13.5)   512x512 3.7 / 3.4 / 3.3 (6.3; lbm_tile_kernel 5.2)
     // K = 2 is HBM-bound, K = 4 instruction-bound at 2 blocks per CU (60 KB frames); K = 3 sits at both limits
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 3), 0), kMaxMultiSteps);
+    c->multi_tail4 = tune_env("LBM_TUNE_MULTI_TAIL4", 1) != 0;
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
@@ -701,8 +703,13 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   int tile_launches = 0;
   const bool multi = c->multi_K > 0 && c->self_periodic;
   for (int t = 0; multi && t < n_steps;) {
-    // up to multi_K steps per pass over HBM (lbm_multi_kernel)
-    const int k = std::min(c->multi_K, n_steps - t);
+    // up to multi_K steps per pass over HBM (lbm_multi_kernel).  A step count that 3 does not divide is split into 3s
+    // and 4s where that avoids the K = 2 / K = 1 launch at the end (8192 x 8192, us per launch: K = 1 870, K = 2 1000,
+    // K = 3 1050, K = 4 1460): n = 3a + 4 for n mod 3 = 1, n = 3a + 8 for n mod 3 = 2.  Whole periodic grids only — a
+    // row partition has K ghost rows, not four.
+    const int left = n_steps - t;
+    int k = std::min(c->multi_K, left);
+    if (c->multi_K == 3 && c->multi_tail4 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
     launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, c->multi_tiles, 0, 0, /*fold=*/true, s);
     c->n_prev = c->multi_tiles; c->n_prev_vecs = k;
     c->parity ^= 1;
