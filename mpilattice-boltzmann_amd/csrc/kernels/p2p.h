@@ -135,46 +135,46 @@ __global__ void __launch_bounds__(64) lbm_p2p_signal_wait_kernel(unsigned long l
   p2p_wait_flags(wait_flags, wait_parity, 2, epoch, parity, timeout_ticks, err);
 }
 
-// One wave: wait until every one of `nflags` flag words has reached `epoch` (acquire, system scope), at
-// most `timeout_ticks` of the 100 MHz wall clock; on time-out set *err (host-visible) to 1 + the index of
-// the missing flag.  With *err already set the kernel returns at once, so a failed run drains quickly.
-// parity_words (may be null; two per flag, indexed by the epoch's parity): the pushers' grid parity must equal
-// `parity` (ranks run in lock step).
-__global__ void __launch_bounds__(64) lbm_p2p_wait_kernel(const unsigned long long* flags, const unsigned long long* parity_words, int nflags,
-                                                           unsigned long long epoch, unsigned long long parity, long long timeout_ticks, int* err)
-{
-  if (threadIdx.x == 0) p2p_wait_flags(flags, parity_words, nflags, epoch, parity, timeout_ticks, err);
-}
+// End-of-run reduction in ONE launch — the reference's MPI_Reduce(MPI_SUM) (d2q9-bgk.c:396) as an all-gather and a
+// local sum in rank order, the same bits on every rank.  Block r copies my per-step sums into slot `my rank` of rank r's
+// window and raises my flag there (stores, barrier, one system-scope release, flag).  Every block then waits until every
+// rank's flag in MY window has reached this round (bounded, as every wait here) and folds its share of the nranks slots
+// into `out`, a host-mapped buffer: no copy kernel, no memcpy.  No block waits for another block of its own launch:
+// what a block waits for is raised by the OTHER ranks' launches and by its own launch's blocks before they wait.
+struct P2PReduceArgs {
+  const double* sums;                        // my per-step sums of this chunk
+  int n, nranks;
+  double* const* slots;                      // [nranks]: rank r's slot for me (this round's parity)
+  unsigned long long* const* flags;          // [nranks]: my flag word in rank r's window
+  unsigned long long round;
+  const unsigned long long* my_flags;        // my window's reduce_flag[nranks]
+  const double* my_slots;                    // my window's slots of this parity, slot_stride doubles apart
+  size_t slot_stride;
+  double* out;                               // host-mapped, n doubles
+  long long timeout_ticks;
+  int* err;
+};
 
-// End-of-run reduction, step 1: my per-step sums into slot `my_rank` of EVERY rank's window (mine included).
-// grid = (ceil(n/256), nranks); slots[r] = rank r's slot for me.
-__global__ void __launch_bounds__(256) lbm_p2p_gather_kernel(const double* sums, int n, double* const* slots)
+__global__ void __launch_bounds__(256) lbm_p2p_allreduce_kernel(const P2PReduceArgs a)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) slots[blockIdx.y][i] = sums[i];
+  const int r = blockIdx.x;
+  double* dst = a.slots[r];
+  for (int i = threadIdx.x; i < a.n; i += 256) dst[i] = a.sums[i];
+  __syncthreads();                                             // every wave's stores have left the CU
+  if (threadIdx.x == 0) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);                   // system scope
+    __hip_atomic_store(a.flags[r], a.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // every block then takes a share of the fold (a run of 80 000 steps reduces 80 000 sums): each waits for itself
+  if (threadIdx.x == 0) p2p_wait_flags(a.my_flags, nullptr, a.nranks, a.round, 0ull, a.timeout_ticks, a.err);
   __syncthreads();
-  if (threadIdx.x == 0) __threadfence_system();
-}
-
-// step 2 (a later kernel of the same stream, so the stores above have been issued and fenced): raise my flag
-// in every rank's window.
-__global__ void __launch_bounds__(64) lbm_p2p_reduce_signal_kernel(unsigned long long* const* flags, int nranks, unsigned long long round)
-{
-  __threadfence_system();
-  if (static_cast<int>(threadIdx.x) < nranks) __hip_atomic_store(flags[threadIdx.x], round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// step 3 (after lbm_p2p_wait_kernel on my nranks reduce flags): out[t] = sum over ranks, in rank order, of
-// slot r's entry t — the reference's MPI_Reduce(MPI_SUM) (d2q9-bgk.c:396), the same bits on every rank.
-__global__ void __launch_bounds__(256) lbm_p2p_fold_kernel(const double* slots, size_t slot_stride, int nranks, int n, double* out)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int r = 0; r < nranks; ++r)
-    s += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slots + r * slot_stride + i), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_SYSTEM));
-  out[i] = s;
+  for (int i = r * 256 + threadIdx.x; i < a.n; i += 256 * a.nranks) {
+    double s = 0.0;
+    for (int q = 0; q < a.nranks; ++q)
+      s += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.my_slots + q * a.slot_stride + i), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_SYSTEM));
+    a.out[i] = s;
+  }
 }
 
 }  // namespace

@@ -61,7 +61,7 @@ struct lbm_p2p {
   const char* window_kind = "coarse";
   int* err = nullptr;                  // host-mapped error word written by the wait kernels
   unsigned int* done = nullptr;        // block-done counter of the push kernel
-  double* reduce_out = nullptr;        // folded global sums of one reduce round (device)
+  double* reduce_out = nullptr;        // folded global sums of one reduce round (host-mapped: the fold kernel writes, the host reads)
   double** d_slots = nullptr;          // device arrays of per-rank pointers, [2 parities][nranks]
   unsigned long long** d_flags = nullptr;
   std::vector<P2PPeer> peers;
@@ -97,7 +97,7 @@ void p2p_unmap(lbm_p2p* t)
 
 // The K rows of the CURRENT grid that the neighbours need, into their ghost rows of the grid with the same
 // parity, flags := epoch; then (same kernel) wait for the neighbours' rows of that epoch to have arrived here.
-int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
+int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s, bool exposed = false)
 {
   lbm_ctx* c = t->ctx;
   const P2PPeer& ps = t->peers[t->south];
@@ -128,7 +128,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s)
   const int work = 18 * (a.nfloats / 2);
   // at most 64 blocks (every block ends with an L2 write-back towards the peers), each lane moving up to four
   // float2's per pass
-  const int max_blocks = t->edge_stream ? t->push_blocks_edge : kP2PPushBlocks;
+  // (`exposed`: the push before the first macro-step of a run, which nothing overlaps)
+  const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge : kP2PPushBlocks;
   const dim3 grid(std::max(1, std::min(max_blocks, (work + 1023) / 1024)));
   hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
   HIP_TRY(hipGetLastError());
@@ -144,15 +145,21 @@ int p2p_reduce(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     const int n = std::min(n_steps - t0, static_cast<int>(t->reduce_cap));
     const unsigned long long round = ++t->reduce_round;
     const int par = static_cast<int>(round & 1);
-    hipLaunchKernelGGL(lbm_p2p_gather_kernel, dim3((n + 255) / 256, t->nranks), dim3(256), 0, cs, c->sums + t0, n, t->d_slots + static_cast<size_t>(par) * t->nranks);
-    hipLaunchKernelGGL(lbm_p2p_reduce_signal_kernel, dim3(1), dim3(64), 0, cs, t->d_flags, t->nranks, round);
-    hipLaunchKernelGGL(lbm_p2p_wait_kernel, dim3(1), dim3(64), 0, cs, header_of(t->window)->reduce_flag, static_cast<const unsigned long long*>(nullptr),
-                       t->nranks, round, 0ull, t->timeout_ticks, t->err);
-    hipLaunchKernelGGL(lbm_p2p_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, cs, slot_of(t->window, t->halo_bytes, t->reduce_cap, t->nranks, par, 0), t->reduce_cap,
-                       t->nranks, n, t->reduce_out);
+    P2PReduceArgs a{};
+    a.sums = c->sums + t0; a.n = n; a.nranks = t->nranks;
+    a.slots = t->d_slots + static_cast<size_t>(par) * t->nranks;
+    a.flags = t->d_flags;
+    a.round = round;
+    a.my_flags = header_of(t->window)->reduce_flag;
+    a.my_slots = slot_of(t->window, t->halo_bytes, t->reduce_cap, t->nranks, par, 0);
+    a.slot_stride = t->reduce_cap;
+    a.out = t->reduce_out;
+    a.timeout_ticks = t->timeout_ticks;
+    a.err = t->err;
+    hipLaunchKernelGGL(lbm_p2p_allreduce_kernel, dim3(t->nranks), dim3(256), 0, cs, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipStreamSynchronize(cs));
+    std::memcpy(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n);     // host-mapped: the kernel wrote it in place
   }
   return 0;
 }
@@ -264,7 +271,7 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   *t->err = 0;
   P2P_TRY(hipMalloc(&t->done, sizeof(unsigned int)));
   P2P_TRY(hipMemset(t->done, 0, sizeof(unsigned int)));
-  P2P_TRY(hipMalloc(&t->reduce_out, sizeof(double) * t->reduce_cap));
+  P2P_TRY(hipHostMalloc(reinterpret_cast<void**>(&t->reduce_out), sizeof(double) * t->reduce_cap, hipHostMallocMapped));
   P2P_TRY(hipMalloc(&t->d_slots, sizeof(double*) * 2 * nranks));
   P2P_TRY(hipMalloc(&t->d_flags, sizeof(unsigned long long*) * nranks));
   P2P_TRY(hipDeviceSynchronize());
@@ -413,7 +420,7 @@ int lbm_p2p_destroy(lbm_p2p* t)
   if (t->window) (void)hipFree(t->window);
   if (t->err) (void)hipHostFree(t->err);
   if (t->done) (void)hipFree(t->done);
-  if (t->reduce_out) (void)hipFree(t->reduce_out);
+  if (t->reduce_out) (void)hipHostFree(t->reduce_out);
   if (t->d_slots) (void)hipFree(t->d_slots);
   if (t->d_flags) (void)hipFree(t->d_flags);
   if (t->edge_done) (void)hipEventDestroy(t->edge_done);
@@ -434,12 +441,14 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
   const int K = c->multi_K;
   hipStream_t cs = t->compute, es = t->edge_stream ? t->edge : t->compute;
   if (begin_run(c, n_steps, cs)) return 1;                     // step-0 accelerate_flow (d2q9-bgk.c:345-348)
-  HIP_TRY(hipEventRecord(t->interior_done, cs));
-  if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
-  // the rows my neighbours need for the first macro-step (the state may have been set since the last run)
+  // the rows my neighbours need for the first macro-step (the state may have been set since the last run, and the
+  // step-0 accelerate_flow has just changed row ny-2).  Nothing overlaps this push: it runs right behind the accelerate
+  // kernel on the compute stream — no hop to the edge stream — with the full complement of blocks.
   unsigned long long epoch = t->epoch + 1;
-  if (p2p_push(t, epoch, es)) return 1;
-  HIP_TRY(hipEventRecord(t->edge_done, es));
+  if (p2p_push(t, epoch, cs, /*exposed=*/true)) return 1;
+  HIP_TRY(hipEventRecord(t->interior_done, cs));
+  HIP_TRY(hipEventRecord(t->edge_done, cs));
+  if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
   const MacroRows rows = macro_rows(c);
   for (int done = 0; done < n_steps; ++epoch) {
     const int k = std::min(K, n_steps - done);
