@@ -55,7 +55,7 @@ struct lbm_p2p {
   hipStream_t compute = nullptr, edge = nullptr;
   hipEvent_t edge_done = nullptr, interior_done = nullptr;
   bool edge_stream = true;             // edge rows on their own stream beside the interior launch
-  int push_blocks_edge = 16;           // blocks of the push kernel when it runs beside the interior launch (LBM_P2P_PUSH_BLOCKS)
+  int push_blocks_edge = 32;           // blocks of the push kernel when it runs beside the interior launch (LBM_P2P_PUSH_BLOCKS)
   char* window = nullptr;              // my exported window: header + reduce slots [2][nranks][cap]
   size_t window_bytes = 0, reduce_cap = 0, halo_bytes = 0;   // halo_bytes: one-step mode's incoming messages, [2 parities][2 dirs][3 * nxp] floats
   const char* window_kind = "coarse";
@@ -243,7 +243,9 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   // beside the interior launch the push has a whole macro-step to finish, and every block of it takes a CU slot and
   // an L2 write-back away from that launch: us/step on a 1-rank ring of 8192 x 1024 rows for 8 / 12 / 16 / 32 / 64
   // blocks 60.1 / 52.8 / 51.7 / 52.1 / 53.6 (8192 x 2048: 94.8 / - / 95.2 / 95.1 / 96.7)
-  t->push_blocks_edge = std::max(1, tune_env("LBM_P2P_PUSH_BLOCKS", 16));
+  // 32, not the 16 that measure best on a self-ring: there the push kernel takes ~110 of the ~147 us it has, and a
+  // real link is slower than local memory — a push that outlasts the interior launch would be the critical path
+  t->push_blocks_edge = std::max(1, tune_env("LBM_P2P_PUSH_BLOCKS", 32));
   auto fail = [&]() { lbm_p2p_destroy(t); return 1; };
 #define P2P_TRY(expr)                                                                        \
   do {                                                                                       \
