@@ -589,6 +589,25 @@ def test_k_steps_per_pass_kernel(lbm, oracle, digests, monkeypatch, name, steps,
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
+@pytest.mark.parametrize("steps", [1, 2, 4, 5, 7, 8, 10, 11, 13])
+@pytest.mark.parametrize("tail4", ["1", "0"])
+def test_run_lengths_that_three_does_not_divide(lbm, oracle, digests, monkeypatch, steps, tail4):
+    """lbm_run at K = 3 splits a step count into 3s and 4s where that avoids a 1- or 2-step launch (n = 3a + 4 or
+    3a + 8; LBM_TUNE_MULTI_TAIL4=0: the plain min(3, left) split).  Either way the state after n steps and the n
+    av_vels are the one-step path's."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MULTI_TAIL4", tail4)
+    p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"] == "lbm_multi_kernel<3>"
+    av = np.concatenate([s.run(steps), s.run(steps)])
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 2 * steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert av.shape == (2 * steps,) and np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
 def _k_step_partitions_in_process(lbm, parts, steps, K):
     """Several K-step partitions of one grid on one GPU, ghost rows exchanged by device copies
     (lbm_macro_exchange_local) in the order of the native loop; returns the summed per-step tot_u."""
