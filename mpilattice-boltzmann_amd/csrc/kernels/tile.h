@@ -34,6 +34,9 @@ constexpr int kMaxTileSteps = 8;
 #ifndef LBM_TILE_STAMPS
 #define LBM_TILE_STAMPS 0
 #endif
+#ifndef LBM_TILE88_BLOCK
+#define LBM_TILE88_BLOCK 512      // lanes of a <8,8> block: 320 would do for its 288 load-phase lanes (1.045 vs 1.009 us/step at 128 x 128; 448: 1.016)
+#endif
 #if LBM_TILE_STAMPS
 __device__ unsigned long long g_tile_stamps[16];
 #define LBM_STAMP(i) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_tile_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -50,8 +53,10 @@ struct TileGeom {
   // 256x256 deck 0.142 -> 0.204 s, 128x128 0.0529 -> 0.0554 — sixteen-wave blocks pay more at the barriers than the
   // shorter chains of the early sub-steps save)
   static constexpr int lanes = RP * R;
-  static constexpr int waves = (lanes + 63) / 64;
-  static constexpr int block = 64 * waves;          // launched size: whole waves (288 -> 320), so that the wave-level sums see 64 active lanes
+  // launched size: whole waves, so that the wave-level sums see 64 active lanes; <8,8> gets 512 lanes rather than the
+  // 320 its load phase needs, so that ALL its sub-steps (regions of 484 cells and less) deal one cell per lane.
+  static constexpr int block = (T == 8 && H == 8 && LBM_TILE88_BLOCK > 64 * ((lanes + 63) / 64)) ? LBM_TILE88_BLOCK : 64 * ((lanes + 63) / 64);
+  static constexpr int waves = block / 64;
   static constexpr size_t lds_bytes = sizeof(float) * 2 * 9 * cells + sizeof(double) * H * waves + cells;   // + flag bytes
   static_assert(lanes <= 1024 && H <= kMaxTileSteps && T % 2 == 0 && H % 2 == 0, "unsupported tile geometry");
 };
@@ -79,7 +84,7 @@ template <int T, int H, bool FULL, bool FAST>   // FULL: this launch does exactl
 __global__ void __launch_bounds__((TileGeom<T, H>::block)) lbm_tile_kernel(const TileArgs a)
 {
   using G = TileGeom<T, H>;
-  constexpr int R = G::R, RP = G::RP, kCells = G::cells, kLanes = G::lanes, kWaves = G::waves, kBlock = G::block;
+  constexpr int R = G::R, RP = G::RP, kCells = G::cells, kWaves = G::waves, kBlock = G::block;
   extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][9][R*R] floats, reduction scratch, flag bytes
   double* red = reinterpret_cast<double*>(lds + 2 * 9 * kCells);    // [H][kWaves]
   uint8_t* cell_flags = reinterpret_cast<uint8_t*>(red + H * kWaves);   // per region cell: bit 0 obstacle, 1 owned, 2 on row ny-2
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__((TileGeom<T, H>::block)) lbm_tile_kernel(const
     // cells still needed after this sub-step: the owned tile expanded by e = k_total - S
     const int e = k_total - S;
     const int side = T + 2 * e;
-    if (side * side <= a.single_max && side * side <= kLanes) {   // block-uniform
+    if (side * side <= a.single_max && side * side <= kBlock) {   // block-uniform
       // Late sub-steps: the region fits the block's SIMDs with one CELL per lane — a wave alone on its SIMD issues an
       // instruction every 4+ cycles whether it is packed or not, so what counts is the length of one lane's chain:
       // ~190 instructions for a cell against ~330 for an x-pair (division, double sqrt and the unaligned LDS

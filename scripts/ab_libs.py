@@ -75,6 +75,7 @@ for r in range(a.rounds):
 ref = digest[ctxs[0][0]]
 for path, lib, ctx in ctxs:
     v = res[path]
+    nd = 1 if min(v) >= 20 else 3
     same = "av==first" if digest[path] == ref else "av DIFFERS from first"
-    print(f"{path.split(':', 1)[0]:>2s} {os.path.basename(path.split(':', 1)[1]):50s} min {min(v):8.1f}  med {statistics.median(v):8.1f}  max {max(v):8.1f} us/step   {same}", flush=True)
+    print(f"{path.split(':', 1)[0]:>2s} {os.path.basename(path.split(':', 1)[1]):50s} min {min(v):8.{nd}f}  med {statistics.median(v):8.{nd}f}  max {max(v):8.{nd}f} us/step   {same}", flush=True)
     lib.lbm_destroy(ctx)
