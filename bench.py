@@ -382,11 +382,13 @@ def main() -> int:
     try:
         times, av = [], None
         for _ in range(max(1, args.reps)):
-            sync_all()
+            sync_all()                                    # barrier + device synchronise: every rank starts together
             t0 = time.perf_counter()
             av = sim.run(args.steps)                      # EXACTLY K steps (+ the av_vels reduction, as the reference times it)
-            sync_all()
-            times.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()                      # this rank's device work is complete (the reduction made it wait for
+            times.append(time.perf_counter() - t0)        # every rank's sums); the MAX over ranks below is the job's time.  The
+            # barrier that closes the bracket is the next repetition's sync_all / the all-reduce of the times: an NCCL barrier
+            # inside the region would add its own ~0.1 ms to a 1 ms region of steps.
             kernel_ms, launches = sim.partition.last_run_kernel_ms()
     except lbm.LbmError as e:
         return fail(f"run: {e}")
@@ -508,7 +510,8 @@ def main() -> int:
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny, "partitioning": part_txt,
                        "loop": what["loop"], "macro_k": what["macro_k"], "rccl_nranks": what["rccl_nranks"], "p2p": what["p2p"],
                        "step_allreduce": what["step_allreduce"], "kernel": desc["kernel"]},
-            "timing": {"reps": len(times), "statistic": "median over reps of (max over ranks of the time of EXACTLY `steps` steps)",
+            "timing": {"reps": len(times), "statistic": "median over reps of (max over ranks of the time of EXACTLY `steps` steps): every rank starts behind a barrier + "
+                                    "device synchronise and stops its clock when its own device work, which ends with the global reduction, is complete",
                        "ms_per_rep": [t * 1e3 for t in times]},
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": roof,
