@@ -336,3 +336,35 @@ def test_enumeration_programs_compile_for_gfx950(tmp_path, name):
     src = os.path.join(ROOT, "scripts", "experiments", name)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", src, "-o", str(tmp_path / "a.out")],
                    check=True, capture_output=True, timeout=600)
+
+
+def test_roofline_json_recomputes_from_the_committed_counter_files():
+    """bench.py's two roofline fractions come from profiles/r02/roofline.json; that file must follow from the rocprofv3
+    --pmc CSVs committed beside it and from nothing else (the formulas of scripts/make_roofline.py, restated here)."""
+    import csv
+    import glob
+    import json
+    d = os.path.join(ROOT, "profiles", "r02")
+    roof = json.load(open(os.path.join(d, "roofline.json")))
+    kernel = roof["kernel_full_name"]
+    mean, dur = {}, {}
+    for f in glob.glob(os.path.join(d, "pmc_*.csv")):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"] == kernel:
+                v, t = acc.setdefault(r["Counter_Name"], ([], []))
+                v.append(float(r["Counter_Value"]))
+                t.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        for name, (v, t) in acc.items():
+            mean[name], dur[name] = sum(v) / len(v), sum(t) / len(t) * 1e-9
+    for name in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"):
+        assert name in mean, name
+    hbm = 2.0 * 1024.0 * mean["FETCH_SIZE"] + 1024.0 * mean["WRITE_SIZE"]
+    assert abs(hbm / roof["hbm_bytes_per_launch"] - 1.0) < 1e-9
+    assert hbm >= 2 * roof["minimum_read_bytes_per_launch"] * 0.99            # every value read once and written once at least
+    clock = mean["GRBM_GUI_ACTIVE"] / 8 / dur["GRBM_GUI_ACTIVE"]
+    frac_valu = 4.0 * mean["SQ_ACTIVE_INST_VALU"] / (dur["SQ_ACTIVE_INST_VALU"] * clock * 1024)
+    assert abs(frac_valu / roof["frac_valu_profiled"] - 1.0) < 1e-9
+    frac_hbm = hbm / (0.5 * (dur["FETCH_SIZE"] + dur["WRITE_SIZE"])) / 8.0e12
+    assert abs(frac_hbm / roof["frac_hbm_physical_profiled"] - 1.0) < 1e-9
+    assert 0.0 < frac_valu < 1.0 and 0.0 < frac_hbm < 1.0                      # fractions of something the chip delivers
