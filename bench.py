@@ -420,7 +420,9 @@ def main() -> int:
             variants = {"fast_av_vels": {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
                                          "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt.astype(np.float64) - av) / av)),
                                          "note": "LBM_FLAG_FAST_AVVELS: each cell's sum|u| term in float instead of double; populations "
-                                                 "identical bit for bit; NOT the headline (default off)"}}
+                                                 "identical bit for bit; NOT the headline (default off).  Measured in a second context of this process: where a "
+                                                 "context's grids land moves its step time by 3-5 % either way (DESIGN.md 4.2), so compare with the "
+                                                 "same-process A/B in profiles/r02/ab_fast_avvels_8192.txt rather than with `value`"}}
         alt.close()
 
     verify = None
