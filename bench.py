@@ -6,9 +6,7 @@
 
 `python bench.py --gpus N` with N > 1 and no rank environment starts the N rank processes itself (a child
 `python -m torch.distributed.run ... bench.py --gpus N ...`, before this process touches the GPU) and relays
-the ONE JSON line; under torch.distributed.run it is a rank.  The N > 1 loops are tried in the order
-p2p, rccl, torch until one completes AND passes the bit-exact check against a single-GPU run; the line says
-which one ran (`config.loop`, `config.rccl_nranks`, `config.macro_k`) and what was tried (`attempts`).
+the ONE JSON line; under torch.distributed.run it is a rank.
 
 Workload (BASELINE.json config 5, the one the metric's targets are quoted on): the synthetic
 8192x8192 deck of SURVEY.md §8(d) — params 8192, 8192, <steps>, 10, 0.1, 0.005, 1.85; walls on the
@@ -16,9 +14,25 @@ four edges plus interior cells blocked i.i.d. with p = 0.005 from splitmix64(see
 state = the reference's uniform equilibrium.  One "step" = one lattice timestep of the WHOLE grid
 (accelerate_flow + fused propagate/rebound/collision/av_velocity, d2q9-bgk.c:345-367).  With N > 1
 ranks the SAME grid is row-partitioned (d2q9-bgk.c:834-862) over the GPUs — strong scaling — with
-a K-row halo exchange per K steps (direct peer-to-peer stores over xGMI, or RCCL send/recv) and one
-reduction of the per-step sums at the end (d2q9-bgk.c:396).  The timed region is the reference's (d2q9-bgk.c:278-398): step loop + av_vels
-reduction, inputs resident in HBM, no file I/O.
+a k-row halo exchange per k steps (direct peer-to-peer stores over xGMI, or RCCL send/recv) and one
+reduction of the per-step sums at the end (d2q9-bgk.c:396).  The timed region is the reference's
+(d2q9-bgk.c:278-398): step loop + av_vels reduction, inputs resident in HBM, no file I/O.
+
+What one N > 1 invocation harvests (each part checked bit for bit against a single-GPU run of the same deck
+on the rank's own device before it is timed, and again after):
+  value / ms_per_step   the headline: loops tried in the order p2p, rccl, torch until one sets up on every
+                        rank, completes the warm-up and passes the check (`exchange_attempts` says what was tried)
+  phases                where a p2p run's time goes (HIP events per rank: set-up, steps, reduction, push kernels)
+  variants.rccl, variants.rccl_step_allreduce
+                        the same deck over the RCCL loop, and with north_star's one all-reduce per (macro-)step
+  secondary.input_1024x1024
+                        BASELINE.json config 4: the shipped 1024x1024 deck, all 20 000 steps, on the same N ranks
+                        (p2p and rccl), Reynolds line and av_vels compared with the reference binary's
+Everything after the headline runs under a time budget (--budget-s): a part that does not fit is recorded as
+skipped, and a watchdog prints the line as far as it got if anything hangs — the driver's run is killed at
+600 s, so the line must be out well before.  The control plane (handles, flags, barriers) is a gloo group:
+its collectives time out with an exception instead of aborting the process, and the peer-to-peer loop then
+does not depend on RCCL at all.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -28,6 +42,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -35,9 +50,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_CELL = 108.0          # 18 reads + 9 writes of fp32 (BASELINE.json north_star)
-PHYS_BYTES_PER_CELL = 72.125         # 9 reads + 9 writes + 1 mask bit actually moved by the pull kernel
+ALGO_BYTES_PER_CELL = 108.0          # 18 reads + 9 writes of fp32 (BASELINE.json north_star, SURVEY.md §8d)
+PHYS_BYTES_PER_CELL = 72.125         # 9 reads + 9 writes + 1 mask bit actually moved by a one-step pull kernel
 HBM_PEAK_GBS = 8000.0                # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r03"                # profiles/<round>/roofline.json: the PMC passes the roofline object rests on
+DECKS = os.path.join(ROOT, "tests", "golden", "decks")
 
 
 def parse_args(argv=None):
@@ -58,10 +75,18 @@ def parse_args(argv=None):
                          "ops; auto = try them in that order")
     ap.add_argument("--step-allreduce", action="store_true",
                     help="RCCL loop: one all-reduce per (macro-)step instead of one after the loop (north_star wording; measured mode)")
-    ap.add_argument("--no-variants", action="store_true", help="N=1: skip the extra timing of the same deck with LBM_FLAG_FAST_AVVELS")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra timings: N=1: LBM_FLAG_FAST_AVVELS; partitioned runs: the RCCL loop and its per-step all-reduce mode")
+    ap.add_argument("--no-secondary", action="store_true", help="partitioned runs: skip the shipped 1024x1024 deck (BASELINE.json config 4)")
+    ap.add_argument("--no-phases", action="store_true", help="skip the profiled extra repetition behind `phases` / the per-launch roofline timing")
+    ap.add_argument("--secondary-steps", type=int, default=0, help="steps of the 1024x1024 deck (default: its own 20 000)")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-exact check against a single-GPU run of the same deck")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the 1-core port sample")
-    ap.add_argument("--launch-timeout", type=float, default=900.0, help="self-launch: seconds before a set of rank processes is given up")
+    ap.add_argument("--budget-s", type=float, default=0.0,
+                    help="seconds this invocation may take before the watchdog prints the line as far as it got (default 420; the "
+                         "driver kills a run at 600).  Optional parts that do not fit are recorded as skipped")
+    ap.add_argument("--launch-timeout", type=float, default=150.0,
+                    help="self-launch: seconds before a set of rank processes is given up (three modes at most: 450 s in the worst case)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="self-launch test: the rank processes only rendezvous (gloo), report their ranks and exit; no GPU is touched")
     args = ap.parse_args(argv)
@@ -157,8 +182,13 @@ def cpu_baseline(lbm, params, obstacles, target_s: float) -> dict:
 
 # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version
 # banner at communicator creation on some boxes), so everything else goes to stderr: fd 1 is pointed at
-# fd 2 for the whole run and the line is written to the saved descriptor.
+# fd 2 for the whole run and the line is written to the saved descriptor — once: by the main thread when
+# it is done, or by the watchdog with what had been banked when the budget ran out.
 REAL_STDOUT = 1
+_EMIT_LOCK = threading.Lock()
+_EMITTED = False
+_BANK: dict | None = None            # rank 0: the line as far as it is complete (the headline at least)
+_STAGE = "start"                     # what the rank is doing (the watchdog names it)
 
 
 def quiet_stdout() -> None:
@@ -168,8 +198,52 @@ def quiet_stdout() -> None:
     os.dup2(2, 1)
 
 
-def emit(obj: dict) -> None:
-    os.write(REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+def emit(obj: dict) -> bool:
+    """Write the line unless one has been written already.  True if this call wrote it."""
+    global _EMITTED
+    with _EMIT_LOCK:
+        if _EMITTED:
+            return False
+        os.write(REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+        _EMITTED = True
+        return True
+
+
+def bank(obj: dict) -> None:
+    global _BANK
+    with _EMIT_LOCK:
+        _BANK = json.loads(json.dumps(obj))          # a copy: later stages keep filling the original
+
+
+def stage(name: str) -> None:
+    global _STAGE
+    _STAGE = name
+
+
+def start_watchdog(rank: int, world: int, budget_s: float, t_start: float) -> None:
+    """A rank that is still running when the budget ends stops itself: rank 0 prints what it has banked (the
+    headline, if that was reached, with a note of what was cut short) or an error line, every rank leaves with
+    os._exit — the only exit that works from under a hung collective or a kernel that never returns."""
+    def watch():
+        while time.time() - t_start < budget_s:
+            time.sleep(0.5)
+        if _EMITTED:
+            return
+        code = 0
+        if rank == 0:
+            banked = _BANK
+            if banked is not None:
+                banked["truncated"] = f"budget of {budget_s:.0f} s ran out during: {_STAGE}"
+                emit(banked)
+            else:
+                emit({"error": f"budget of {budget_s:.0f} s ran out during: {_STAGE}", "n_gpus": world})
+                code = 1
+        else:
+            time.sleep(1.0)                          # let rank 0 write first: its exit ends the launcher's wait
+        sys.stderr.write(f"bench.py: rank {rank}: budget of {budget_s:.0f} s ran out during: {_STAGE}\n")
+        sys.stderr.flush()
+        os._exit(code)
+    threading.Thread(target=watch, daemon=True).start()
 
 
 def free_port() -> int:
@@ -179,6 +253,15 @@ def free_port() -> int:
         return sock.getsockname()[1]
 
 
+def launch_modes(args) -> list[str]:
+    """Exchange modes the self-launcher tries, one set of rank processes each.  auto: the ranks themselves try
+    p2p, rccl, torch in turn; this level only steps in when a whole set of rank processes crashed or hung, and then
+    pins the mode.  The worst case is len(modes) x --launch-timeout seconds (tests pin: < 500 s with the defaults)."""
+    if args.dry_launch:
+        return [args.exchange]
+    return [args.exchange] if args.exchange != "auto" else ["auto", "rccl", "torch"]
+
+
 def self_launch(args, argv) -> int:
     """`python bench.py --gpus N` outside torch.distributed.run: start the N rank processes as a CHILD
     `python -m torch.distributed.run` (the reference's `mpirun -np N`, mpi_submit:63) and relay its one JSON
@@ -186,23 +269,21 @@ def self_launch(args, argv) -> int:
     fails its bit-exact check is followed by the next exchange mode, and the line records every attempt."""
     import signal
     import subprocess
-    # auto: the ranks themselves try p2p, rccl, torch in turn (each attempt checked against a single-GPU run);
-    # this level only steps in when a whole set of rank processes crashed or hung, and then pins the mode
-    modes = [args.exchange] if args.exchange != "auto" else ["auto", "rccl", "torch"]
-    if args.dry_launch:
-        modes = modes[:1]
     attempts = []
-    clean, skip = [], False                     # argv without any --exchange option
+    clean, skip = [], False                     # argv without any --exchange / --budget-s option
     for a in argv:
         if skip:
             skip = False
-        elif a == "--exchange":
+        elif a in ("--exchange", "--budget-s"):
             skip = True
-        elif not a.startswith("--exchange="):
+        elif not a.startswith("--exchange=") and not a.startswith("--budget-s="):
             clean.append(a)
-    for mode in modes:
+    # the ranks' own budget ends before this level gives up on them, so that a slow run still returns its headline
+    budget = args.budget_s if args.budget_s > 0 else max(30.0, args.launch_timeout - 25.0)
+    for mode in launch_modes(args):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *clean, "--exchange", mode]
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *clean, "--exchange", mode,
+               "--budget-s", str(min(budget, max(30.0, args.launch_timeout - 25.0)))]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL and hipIpc* across rank processes need it
         t0 = time.time()
@@ -226,7 +307,8 @@ def self_launch(args, argv) -> int:
                 except ValueError:
                     pass
         attempt = {"exchange": mode, "returncode": rc, "seconds": round(time.time() - t0, 1)}
-        good = rc == 0 and isinstance(line, dict) and ("value" in line or line.get("dry_launch"))
+        # a line with a value counts even when the launcher had to be killed afterwards (a rank stuck in tear-down)
+        good = isinstance(line, dict) and ("value" in line or (rc == 0 and line.get("dry_launch")))
         if not good:
             attempt["error"] = "timed out" if rc == -9 else (line or {}).get("error", "no result line")
         attempts.append(attempt)
@@ -252,22 +334,97 @@ def dry_rank() -> None:
     dist.destroy_process_group()
 
 
-def load_roofline(kernel: str, workload: str) -> dict | None:
-    """Per-launch HBM bytes and VALU cycles of the dominant kernel from the PMC passes of this commit
-    (profiles/r02/roofline.json, written by scripts/make_roofline.py from the rocprofv3 CSVs beside it)."""
-    path = os.path.join(ROOT, "profiles", "r02", "roofline.json")
-    if not os.path.exists(path):
-        return None
+def load_roofline() -> dict | None:
+    """Per-launch HBM bytes and VALU busy cycles of the step kernels from the PMC passes of this round
+    (profiles/<round>/roofline.json, written by scripts/make_roofline.py from the rocprofv3 CSVs beside it)."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "roofline.json")
     try:
-        r = json.load(open(path))
-    except ValueError:
+        return json.load(open(path))
+    except (OSError, ValueError):
         return None
-    return r if r.get("kernel") == kernel and r.get("workload") == workload else None
+
+
+def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, launch_profile, avg_launch_s: float, launches: int,
+                    steps: int, pmc: dict | None, scale: float = 1.0) -> dict:
+    """The `roofline` object of the line.  launch_profile: [(steps advanced, us)] per step-kernel launch of a profiled
+    repetition of this very run (HIP events on the kernels' stream), or None: then only the whole-run average is known.
+    `scale`: a rank's launches advance `scale` x the cells the PMC passes profiled (partitioned runs of the same kernel).
+
+      achieved / peak / frac / traffic   the DOMINANT kernel (the instantiation that advances most of the steps):
+                                         PHYSICAL HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate
+                                         passes, profiles/<round>/) over that kernel's average launch duration in THIS run
+      by_section_8d                      SURVEY.md §8(d)'s own accounting: 108 B x cells x steps of the launch over the same
+                                         duration — exceeds 1 because lbm_multi_kernel<K> makes one HBM pass per K steps
+      run_mix                            every instantiation the run launched (a 20-step run is 4 x K=3 + 2 x K=4): launches,
+                                         live duration, profiled bytes; frac_hbm_physical_run = all bytes over all kernel time
+      limits.valu                        VALU busy share of a PROFILED pass (a constant of the commit, not of this run)"""
+    by_k: dict[int, list[float]] = {}
+    if launch_profile:
+        for k, us in launch_profile:
+            by_k.setdefault(int(k), []).append(float(us))
+    kernels = (pmc or {}).get("kernels", {})
+    family = kernel.split("<")[0]
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel,
+            "launches": launches, "avg_launch_ms_whole_run": avg_launch_s * 1e3}
+    if not by_k:
+        # no per-launch timing (partitioned run): the whole run's average launch, the run's average steps per launch
+        spl = steps / max(launches, 1)
+        algo = ALGO_BYTES_PER_CELL * cells_per_launch * spl / avg_launch_s / 1e9
+        roof["by_section_8d"] = {"achieved": algo, "frac": algo / HBM_PEAK_GBS, "unit": "GB/s", "steps_per_launch": spl,
+                                 "note": "108 B x cells x steps per launch / average launch time; exceeds 1: one HBM pass per K steps"}
+        entry = kernels.get(kernel)
+        if entry:
+            hbm = entry["hbm_bytes_per_launch"] * scale * (spl / entry["steps_per_launch"])
+            roof.update({"achieved": hbm / avg_launch_s / 1e9, "frac": hbm / avg_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": hbm,
+                         "scaled_from_single_gpu_pmc": True,
+                         "note": "a rank's launches run the profiled kernel on fewer tiles: its per-launch bytes scaled by the cells and "
+                                 "steps a launch advances here, over this run's average launch time"})
+        return roof
+    dominant = max(by_k, key=lambda k: k * len(by_k[k]))
+    mix, bytes_run, time_run = {}, 0.0, 0.0
+    for k, durs in sorted(by_k.items()):
+        name = f"{family}<{k}>" if "multi" in family or "tile" in family else kernel
+        t = sum(durs) / len(durs) * 1e-6
+        entry = kernels.get(name)
+        m = {"kernel": name, "launches": len(durs), "avg_launch_ms": t * 1e3, "min_launch_ms": min(durs) * 1e-3,
+             "by_section_8d_frac": ALGO_BYTES_PER_CELL * cells_per_launch * k / t / 1e9 / HBM_PEAK_GBS}
+        if entry:
+            hbm = entry["hbm_bytes_per_launch"] * scale
+            m.update({"hbm_bytes_per_launch": hbm, "hbm_GBps": hbm / t / 1e9, "frac_hbm_physical": hbm / t / 1e9 / HBM_PEAK_GBS,
+                      "bytes_per_cell_step": hbm / (cells_per_launch * k)})
+            bytes_run += hbm * len(durs)
+            time_run += t * len(durs)
+        mix[f"K{k}"] = m
+    d = mix[f"K{dominant}"]
+    roof.update({"kernel": d["kernel"], "avg_launch_ms": d["avg_launch_ms"], "steps_per_launch": dominant, "run_mix": mix,
+                 "by_section_8d": {"achieved": d["by_section_8d_frac"] * HBM_PEAK_GBS, "frac": d["by_section_8d_frac"], "unit": "GB/s",
+                                   "bytes_per_launch": ALGO_BYTES_PER_CELL * cells_per_launch * dominant,
+                                   "note": "SURVEY.md §8(d): 108 B (18 reads + 9 writes) x cells x steps of the launch / its average "
+                                           "duration / 8 TB/s; exceeds 1: lbm_multi_kernel<K> makes one HBM pass per K steps"}})
+    if "hbm_bytes_per_launch" in d:
+        roof.update({"achieved": d["hbm_GBps"], "frac": d["frac_hbm_physical"], "traffic": d["hbm_bytes_per_launch"],
+                     "frac_hbm_physical": d["frac_hbm_physical"],
+                     "frac_hbm_physical_run": (bytes_run / time_run / 1e9 / HBM_PEAK_GBS) if time_run > 0 else None,
+                     "pmc_source": f"profiles/{PROFILE_ROUND}/roofline.json (scripts/make_roofline.py over the rocprofv3 --pmc CSVs beside it)",
+                     "note": "achieved = PHYSICAL HBM bytes per launch of the dominant kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate "
+                             "passes) / its average launch duration in this run (HIP events around every launch of a profiled repetition); "
+                             "frac = achieved / 8 TB/s; traffic = those bytes"})
+        entry = kernels.get(d["kernel"], {})
+        if "frac_valu_profiled" in entry:
+            roof["limits"] = {"hbm": {"achieved": d["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac_hbm_physical"]},
+                              "valu": {"frac": entry["frac_valu_profiled"], "kind": "profiled-pass constant",
+                                       "note": "4 x SQ_ACTIVE_INST_VALU busy cycles over the cycles of the SAME profiled pass (GRBM_GUI_ACTIVE / 8 "
+                                               "XCDs x 1024 SIMDs): a property of the commit's kernel, it does not move with this run's timing"}}
+            roof["lds_bank_conflict_frac"] = entry.get("lds_bank_conflict_frac")
+    else:
+        roof["note"] = f"no PMC summary for {d['kernel']} in profiles/{PROFILE_ROUND}/roofline.json: only the §8(d) figure"
+    return roof
 
 
 def main() -> int:
     argv = sys.argv[1:]
     args = parse_args(argv)
+    t_start = time.time()
     quiet_stdout()
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not in_rank and (args.gpus > 1 or args.dry_launch):
@@ -282,18 +439,38 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    budget = args.budget_s if args.budget_s > 0 else 420.0
+    start_watchdog(rank, world, budget, t_start)
 
+    def left() -> float:
+        return budget - (time.time() - t_start)
+
+    stage("import torch")
+    import datetime
     import torch
     import mpilattice_boltzmann_amd as lbm
     torch.cuda.set_device(local_rank)
+    # a device-side wait of the peer-to-peer loop gives up after this long (a failed or missing peer, or ranks entering a
+    # run this far apart): 10 s keeps a dead transport from eating the budget the fall-backs need
+    os.environ.setdefault("LBM_P2P_TIMEOUT_MS", "10000")
     dist = None
-    backend = os.environ.get("LBM_DIST_BACKEND", "nccl")   # "gloo": ranks may share a GPU (p2p exchange only; testing aid)
+    # Control plane: gloo (LBM_DIST_BACKEND=nccl selects torch's NCCL group instead).  Handles, agreement flags and
+    # barriers are host objects; gloo's collectives time out with an exception where an NCCL collective that never
+    # completes takes the process down, and with gloo the peer-to-peer loop needs no RCCL anywhere.  The RCCL loop
+    # brings its own communicator (ncclCommInitRank on an id passed over this group); the torch loop, the last resort,
+    # then stages its halo rows through the host.
+    backend = os.environ.get("LBM_DIST_BACKEND", "gloo")
     if world > 1:
+        stage("process group")
         import torch.distributed as dist
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # one node: the loopback interface always resolves
+        ctl_timeout = datetime.timedelta(seconds=max(30.0, min(120.0, budget / 3)))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=ctl_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=ctl_timeout)
+    on_host = backend != "nccl"
+    stage("build")
     if rank == 0:
         lbm.build()                                       # no-op when lib/ is current; other ranks wait below
     if dist is not None:
@@ -301,6 +478,7 @@ def main() -> int:
     lbm.load_library()
     nx, ny = (int(v) for v in args.workload.lower().split("x"))
     params = lbm.Params(nx, ny, args.steps, 10, 0.1, 0.005, 1.85)
+    stage("synthetic deck")
     obstacles = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
     flags = lbm._capi.FLAG_FORCE_HALO if args.ring else 0
     partitioned = world > 1 or args.ring
@@ -310,16 +488,41 @@ def main() -> int:
         if rank == 0:
             emit({"error": message, "n_gpus": world, "exchange": args.exchange})
         if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:           # noqa: BLE001 - a rank is gone: nothing to meet
+                pass
         return 1
 
-    def all_ok(flag: bool) -> bool:
+    def agree(flag: bool) -> bool:
+        """True iff true on every rank."""
         if dist is None:
             return flag
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if backend == "gloo" else "cuda")
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if on_host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
+
+    def min_over_ranks(v: float) -> float:
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if on_host else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def max_over_ranks(values: list[float]) -> list[float]:
+        if dist is None:
+            return values
+        t = torch.tensor(values, dtype=torch.float64, device="cpu" if on_host else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+    def gather(obj) -> list:
+        if dist is None:
+            return [obj]
+        box = [None] * world
+        dist.all_gather_object(box, obj)
+        return box
 
     def sync_all():
         torch.cuda.synchronize()
@@ -327,108 +530,142 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def check_against_single_gpu(sim, av_last, steps_done):
+    # ---- the single-GPU reference every partitioned run is checked against, computed once per (deck, step count) ----
+    ref_cache: dict = {}
+
+    def single_gpu_reference(p, obst, steps_done: int, y0: int, y1: int, n_av: int):
+        """(digest of rows [y0, y1), last n_av av_vels) of ONE GPU doing the whole grid for steps_done steps."""
+        key = (p.nx, p.ny, steps_done)
+        if key not in ref_cache:
+            whole = lbm.Simulation(p, obst, device=local_rank)
+            av = whole.run(steps_done)
+            ref_cache[key] = (whole.partition.checksum(y0, y1), av)
+            whole.close()
+        digest, av = ref_cache[key]
+        return digest, av[len(av) - n_av:] if n_av else np.zeros(0, np.float32)
+
+    def check_against_single_gpu(sim, p, obst, av_last, steps_done):
         """The partitioned run against ONE GPU doing the whole grid, bit for bit: 64-bit digest of this rank's
         rows (lbm_state_checksum) and the last run's av_vels — the multi-GPU parity test, run where the GPUs are."""
-        whole = lbm.Simulation(params, obstacles, device=local_rank)
-        av_ref = whole.run(steps_done)[-len(av_last):] if len(av_last) else np.zeros(0, np.float32)
         y0, y1 = sim.partition.y0, sim.partition.y0 + sim.partition.ny_local
-        same = sim.partition.checksum() == whole.partition.checksum(y0, y1)
-        whole.close()
+        digest, av_ref = single_gpu_reference(p, obst, steps_done, y0, y1, len(av_last))
+        same = sim.partition.checksum() == digest
         av_err = float(np.max(np.abs(av_last.astype(np.float64) - av_ref.astype(np.float64)) / av_ref.astype(np.float64))) if len(av_last) else 0.0
         return bool(same and av_err < 1e-6), same, av_err
 
-    # Which loop runs.  strict: what is asked for runs or the attempt fails — never a silent fall-back inside
-    # Simulation, which would be reported as the faster loop at a fraction of its speed.  With --exchange auto
-    # the loops are tried in turn HERE, visibly: each must set up on every rank, complete the warm-up and
-    # reproduce a single-GPU run of the same deck bit for bit before it is timed.
     verify_on = partitioned and not args.no_verify
+
+    def set_up(p, obst, mode: str, step_allreduce: bool, warmup: int, fl: int):
+        """One loop on every rank: create, warm up, check.  Returns (sim or None, note) — rank-symmetric."""
+        note, ok, sim = None, False, None
+        try:
+            sim = lbm.Simulation(p, obst, device=local_rank, flags=fl, distributed=world > 1, exchange=mode, strict=True,
+                                 step_allreduce=step_allreduce)
+            ok = True
+        except lbm.LbmError as e:                         # raised on every rank together
+            sim, note = None, f"set-up: {e}"
+        if ok:
+            try:
+                av_w = sim.run(warmup)                    # untimed
+                if verify_on:
+                    good, same, av_err = check_against_single_gpu(sim, p, obst, av_w, warmup)
+                    if not good:
+                        ok, note = False, f"parity after the warm-up: state digest equal {same}, av_vels rel err {av_err:.2e}"
+            except lbm.LbmError as e:
+                ok, note = False, f"warm-up: {e}"
+        ok = agree(ok)
+        if not ok and sim is not None:
+            sim.close()
+            sim = None
+        return sim, (None if ok else (note or "failed on another rank"))
+
+    def timed(sim, steps: int, reps: int):
+        """reps x (barrier + device sync; EXACTLY `steps` steps + the reduction; device sync) -> per-rep seconds, MAX over
+        ranks; last av_vels.  The barrier that closes one bracket is the next repetition's: an NCCL barrier inside the
+        region would add its own ~0.1 ms to a 1 ms region of steps."""
+        times, av = [], None
+        for _ in range(max(1, reps)):
+            sync_all()
+            t0 = time.perf_counter()
+            av = sim.run(steps)
+            torch.cuda.synchronize()                      # this rank's device work is complete: the reduction made it wait
+            times.append(time.perf_counter() - t0)        # for every rank's sums
+        return max_over_ranks(times), av
+
+    # ---- headline ----------------------------------------------------------------------------------------------
     if not partitioned:
         modes = ["auto"]
     elif args.exchange != "auto":
         modes = [args.exchange]
     else:
         modes = ["rccl"] if args.step_allreduce else ["p2p", "rccl", "torch"]
+    # ranks that share a device (testing aid) cannot form an RCCL communicator: said up front, not found out by a hang
+    devices = gather((os.uname().nodename, local_rank))
+    shared_gpu = len(set(devices)) < len(devices)
     attempts, sim = [], None
     for mode in modes:
-        note, ok = None, False
-        try:
-            sim = lbm.Simulation(params, obstacles, device=local_rank, flags=flags, distributed=world > 1, exchange=mode,
-                                 strict=True, step_allreduce=args.step_allreduce)
-            ok = True
-        except lbm.LbmError as e:                         # raised on every rank together
-            sim, note = None, f"set-up: {e}"
-        if ok:
-            try:
-                av_w = sim.run(args.warmup)               # untimed
-                if verify_on:
-                    good, same, av_err = check_against_single_gpu(sim, av_w, args.warmup)
-                    if not good:
-                        ok, note = False, f"parity after the warm-up: state digest equal {same}, av_vels rel err {av_err:.2e}"
-            except lbm.LbmError as e:
-                ok, note = False, f"warm-up: {e}"
-        ok = all_ok(ok)
-        attempts.append({"exchange": mode, "ok": ok, **({"error": note or "failed on another rank"} if not ok else {})})
-        if ok:
-            break
+        stage(f"headline: {mode} loop set-up and warm-up")
+        if mode == "rccl" and shared_gpu:
+            attempts.append({"exchange": mode, "ok": False, "error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"})
+            continue
+        sim, note = set_up(params, obstacles, mode, args.step_allreduce, args.warmup, flags)
+        attempts.append({"exchange": mode, "ok": sim is not None, **({"error": note} if sim is None else {})})
         if sim is not None:
-            sim.close()
-            sim = None
+            break
         if rank == 0:
-            sys.stderr.write(f"bench.py: exchange={mode} not usable ({attempts[-1]['error']}); trying the next one\n")
+            sys.stderr.write(f"bench.py: exchange={mode} not usable ({note}); trying the next one\n")
     if sim is None:
         return fail("no exchange mode completed: " + json.dumps(attempts))
 
+    stage("headline: timed repetitions")
     try:
-        times, av = [], None
-        for _ in range(max(1, args.reps)):
-            sync_all()                                    # barrier + device synchronise: every rank starts together
-            t0 = time.perf_counter()
-            av = sim.run(args.steps)                      # EXACTLY K steps (+ the av_vels reduction, as the reference times it)
-            torch.cuda.synchronize()                      # this rank's device work is complete (the reduction made it wait for
-            times.append(time.perf_counter() - t0)        # every rank's sums); the MAX over ranks below is the job's time.  The
-            # barrier that closes the bracket is the next repetition's sync_all / the all-reduce of the times: an NCCL barrier
-            # inside the region would add its own ~0.1 ms to a 1 ms region of steps.
-            kernel_ms, launches = sim.partition.last_run_kernel_ms()
+        times, av = timed(sim, args.steps, args.reps)
+        kernel_ms, launches = sim.partition.last_run_kernel_ms()
     except lbm.LbmError as e:
         return fail(f"run: {e}")
-    if dist is not None:                                  # per repetition: the slowest rank's time
-        t = torch.tensor(times, dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        times = [float(v) for v in t.cpu()]
     elapsed = float(np.median(times))
     assert av.shape == (args.steps,) and np.all(np.isfinite(av)) and np.all(av > 0)
-
     desc = sim.partition.describe()
     what = sim.describe()
     steps_done = args.warmup + args.steps * max(1, args.reps)
 
-    # N = 1: the same deck with LBM_FLAG_FAST_AVVELS (float sum|u| terms; default off) — both figures side by side
-    variants = None
-    if world == 1 and not args.ring and not args.no_variants:
-        alt = lbm.Simulation(params, obstacles, device=local_rank, flags=flags | lbm._capi.FLAG_FAST_AVVELS)
-        if "fast av_vels" in alt.partition.describe()["kernel"]:
-            alt.run(args.warmup)
-            talt, av_alt = [], None
-            for _ in range(max(1, args.reps)):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                av_alt = alt.run(args.steps)
-                torch.cuda.synchronize()
-                talt.append(time.perf_counter() - t0)
-            med = float(np.median(talt))
-            variants = {"fast_av_vels": {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
-                                         "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt.astype(np.float64) - av) / av)),
-                                         "note": "LBM_FLAG_FAST_AVVELS: each cell's sum|u| term in float instead of double; populations "
-                                                 "identical bit for bit; NOT the headline (default off).  Measured in a second context of this process: where a "
-                                                 "context's grids land moves its step time by 3-5 % either way (DESIGN.md 4.2), so compare with the "
-                                                 "same-process A/B in profiles/r02/ab_fast_avvels_8192.txt rather than with `value`"}}
-        alt.close()
+    # one more repetition with HIP events around every launch: the per-kernel launch durations behind `roofline`
+    # (single GPU) or where a rank's run goes (`phases`, peer-to-peer loop).  Not timed: the events perturb the schedule.
+    launch_profile, phases = None, None
+    if not args.no_phases:
+        stage("profiled repetition")
+        try:
+            if not partitioned:
+                sim.partition.set_profile(True)
+                sim.run(args.steps)
+                launch_profile = sim.partition.launch_profile()
+                sim.partition.set_profile(False)
+                steps_done += args.steps
+            elif what["loop"] == "p2p":
+                sim._p2p.set_profile(True)
+                sync_all()
+                av = sim.run(args.steps)
+                mine = sim._p2p.phases()
+                sim._p2p.set_profile(False)
+                steps_done += args.steps
+                every = gather(mine)
+                names = list(mine)
+                phases = {"unit": "us (macro_steps: a count)", "steps": args.steps,
+                          "max_over_ranks": {n: max(r[n] for r in every) for n in names},
+                          "mean_over_ranks": {n: sum(r[n] for r in every) / len(every) for n in names},
+                          "per_rank": every,
+                          "note": "one extra repetition with HIP timing events around every launch (lbm_p2p_set_profile): setup = run "
+                                  "start -> first step kernel; macro_step_steady = interior launch to interior launch without the first "
+                                  "and last macro-step; push_* = the push kernel INCLUDING its wait for both neighbours' rows; reduce = "
+                                  "last step kernel -> global sums in host memory; host_overhead = wall time of the call - device span"}
+        except lbm.LbmError as e:
+            return fail(f"profiled run: {e}")
 
     verify = None
     if verify_on:
-        good, same, av_err = check_against_single_gpu(sim, av, steps_done)
-        good = all_ok(good)
+        stage("headline: parity check")
+        good, same, av_err = check_against_single_gpu(sim, params, obstacles, av, steps_done)
+        good = agree(good)
         verify = {"ok": good, "what": f"every rank's rows bit-identical (64-bit state digest) to a single-GPU run of the whole grid on the same "
                                       f"device, after the warm-up ({args.warmup} steps) and after all {steps_done} steps; av_vels of the last "
                                       f"repetition within 1e-6", "av_vels_max_rel": av_err}
@@ -438,72 +675,33 @@ def main() -> int:
                         f"(state digest equal: {same}, av_vels rel err {av_err:.2e})")
     sim.close()
 
+    out = None
     if rank == 0:
         cells = nx * ny
         mlups = cells * args.steps / elapsed / 1e6
-        # dominant kernel: the fused step kernel; average launch duration from HIP events on its stream (last repetition).
-        # A launch of lbm_multi_kernel<K> advances its cells by K steps, so the algorithmic bytes of a
-        # launch are 108 B x cells x steps-per-launch (the convention counts traffic per cell-STEP).
-        avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
+        # a macro-step of the edge-stream schedule is two concurrent launches (interior + edge tiles): counted as ONE
+        # launch over all of the rank's cells, so that bytes and time refer to the same thing
         two_launches = partitioned and (what["p2p"] is None or "edge stream" in what["p2p"])
-        if not two_launches:
-            cells_per_launch = desc["cells_per_launch"]
-            steps_per_launch = args.steps / max(launches, 1)
-        else:                                             # interior + edge launch per (macro-)step on this rank
-            cells_per_launch = desc["cells_per_launch"] / 2.0
-            steps_per_launch = args.steps / max(launches / 2.0, 1)
-        algo_gbs = ALGO_BYTES_PER_CELL * cells_per_launch * steps_per_launch / avg_launch_s / 1e9
-        # The binding limits, from PMC passes of this commit (profiles/r02/): physical HBM bytes and VALU busy
-        # cycles per launch, each against this run's launch time.  `frac` is the larger of the two: a fraction
-        # of something the chip can actually deliver.  The 108-B convention figure (which assumes one pass over
-        # HBM per step, while this kernel makes one per K steps) is reported beside it, not as `frac`.
-        pmc = load_roofline(desc["kernel"], f"{nx}x{ny}") if (world == 1 and not args.ring) else None
-        # partitioned runs of the same kernel: the per-launch counters scale with the cells a launch advances (the PMC
-        # passes profile one process on the whole 8192x8192 grid; a rank's launches run the same code on fewer tiles)
-        scaled = None
-        if pmc is None and partitioned:
-            whole = load_roofline(desc["kernel"], "8192x8192")
-            if whole is not None:
-                scale = cells_per_launch * steps_per_launch / (8192.0 * 8192.0 * whole["steps_per_launch"])
-                scaled = dict(whole, hbm_bytes_per_launch=whole["hbm_bytes_per_launch"] * scale)
-                pmc = scaled
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": desc["kernel"], "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "steps_per_launch": steps_per_launch,
-                "convention_108B": {"GBps": algo_gbs, "ratio_to_peak": algo_gbs / HBM_PEAK_GBS, "bytes_per_cell_step": ALGO_BYTES_PER_CELL,
-                                    "note": "north_star's accounting (18 reads + 9 writes per cell per step); exceeds 1 because "
-                                            "lbm_multi_kernel makes one pass over HBM per K steps"}}
-        if pmc is not None:
-            hbm_gbs = pmc["hbm_bytes_per_launch"] / avg_launch_s / 1e9
-            frac_hbm = hbm_gbs / HBM_PEAK_GBS
-            # VALU: busy cycles over available cycles, both counted in ONE profiled pass (4 x SQ_ACTIVE_INST_VALU over
-            # GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): a ratio of cycles, so it does not depend on the clock the chip
-            # holds (profiled passes run ~8 % slower than this un-profiled run, at a lower clock)
-            frac_valu = pmc["frac_valu_profiled"]
-            simds = pmc.get("simds", 1024)
-            limits = {"hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm},
-                      "valu": {"achieved": frac_valu * simds, "peak": float(simds), "unit": "busy SIMDs", "frac": frac_valu}}
-            bound = "hbm" if frac_hbm >= frac_valu else "valu"
-            roof.update(limits[bound])
-            roof.update({"bound": bound, "traffic": pmc["hbm_bytes_per_launch"], "frac_hbm_physical": frac_hbm, "frac_valu": frac_valu,
-                         "limits": limits, "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"),
-                         "scaled_from_single_gpu_pmc": scaled is not None,
-                         "pmc_source": "profiles/r02/roofline.json (scripts/make_roofline.py over the rocprofv3 --pmc CSVs beside it)",
-                         "note": "two limits, each a fraction of something the chip can deliver; achieved/peak/frac are those of the larger "
-                                 "(`bound`).  hbm: physical bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes) over THIS "
-                                 "run's launch time, against 8 TB/s.  valu: 4 x SQ_ACTIVE_INST_VALU busy cycles per launch over the cycles of the "
-                                 "same profiled pass (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs — a cycle ratio, independent of the clock held"})
-        else:
-            roof.update({"achieved": algo_gbs, "frac": None,
-                         "note": "no PMC summary for this kernel/workload in profiles/r02/roofline.json: only the 108-B convention figure"})
+        n_launch = max(launches // 2 if two_launches else launches, 1)
+        avg_launch_s = kernel_ms / 1e3 / n_launch
+        cells_per_launch = float(desc["cells_per_launch"])
+        pmc = load_roofline()
+        scale = 1.0
+        if partitioned and pmc is not None:
+            pnx, pny = (int(v) for v in pmc.get("workload", "8192x8192").split("x"))
+            scale = cells_per_launch / float(pnx * pny)
+        elif pmc is not None and pmc.get("workload") != f"{nx}x{ny}":
+            pmc = None
+        roof = roofline_object(desc["kernel"], nx, ny, cells_per_launch, launch_profile, avg_launch_s, n_launch, args.steps, pmc, scale)
         exchange_txt = {"p2p": "direct peer-to-peer stores into the neighbours' ghost rows (xGMI), flags + one-wave wait kernels, "
                                "all-gather + local sum after the loop",
                         "rccl": "RCCL send/recv on a side stream, " + ("one all-reduce per macro-step" if what["step_allreduce"] else "one all-reduce after the loop"),
                         "torch": "torch.distributed P2P ops, one all-reduce after the loop", "single": ""}[what["loop"]]
         k = max(what["macro_k"], 1)
         if world == 1:
-            part_txt = "single GPU" if not args.ring else f"1-rank ring (self exchange), {k}-row halo exchange per {k} steps: {exchange_txt}"
+            part_txt = "single GPU" if not args.ring else f"1-rank ring (self exchange), one k-row halo exchange per macro-step of k steps (K = {k}): {exchange_txt}"
         else:
-            part_txt = f"{world} row blocks (d2q9-bgk.c:834-862), one {k}-row halo exchange per {k} steps: {exchange_txt}"
+            part_txt = f"{world} row blocks (d2q9-bgk.c:834-862), one k-row halo exchange per macro-step of k steps (K = {k}): {exchange_txt}"
         out = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -511,25 +709,136 @@ def main() -> int:
             "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny, "partitioning": part_txt,
                        "loop": what["loop"], "macro_k": what["macro_k"], "rccl_nranks": what["rccl_nranks"], "p2p": what["p2p"],
-                       "step_allreduce": what["step_allreduce"], "kernel": desc["kernel"]},
+                       "step_allreduce": what["step_allreduce"], "kernel": desc["kernel"], "control_plane": backend if world > 1 else None},
             "timing": {"reps": len(times), "statistic": "median over reps of (max over ranks of the time of EXACTLY `steps` steps): every rank starts behind a barrier + "
                                     "device synchronise and stops its clock when its own device work, which ends with the global reduction, is complete",
                        "ms_per_rep": [t * 1e3 for t in times]},
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": roof,
         }
-        if variants is not None:
-            out["variants"] = variants
+        if phases is not None:
+            out["phases"] = phases
         if verify is not None:
             out["parity_check"] = verify
         if partitioned:
             out["exchange_attempts"] = attempts
-        if world == 1 and not args.no_cpu_baseline:
+        bank(out)                                          # from here on the watchdog has a line to print
+
+    # ---- N = 1: the same deck with LBM_FLAG_FAST_AVVELS (float sum|u| terms; default off) ---------------------------
+    if world == 1 and not args.ring and not args.no_variants:
+        stage("variant: fast av_vels")
+        variants = None
+        alt = lbm.Simulation(params, obstacles, device=local_rank, flags=flags | lbm._capi.FLAG_FAST_AVVELS)
+        if "fast av_vels" in alt.partition.describe()["kernel"]:
+            alt.run(args.warmup)
+            talt, av_alt = timed(alt, args.steps, args.reps)
+            med = float(np.median(talt))
+            variants = {"fast_av_vels": {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
+                                         "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt.astype(np.float64) - av) / av)),
+                                         "note": "LBM_FLAG_FAST_AVVELS: each cell's sum|u| term in float instead of double; populations "
+                                                 "identical bit for bit; NOT the headline (default off).  Measured in a second context of this process: where a "
+                                                 "context's grids land moves its step time by 3-5 % either way (DESIGN.md 4.2), so compare with a "
+                                                 "same-process A/B (scripts/ab_libs.py) rather than with `value`"}}
+        alt.close()
+        if variants is not None:
+            out["variants"] = variants
+            bank(out)
+
+    # ---- partitioned runs: the RCCL loop, and north_star's per-step all-reduce, on the same deck -----------------------
+    def optional_part(name: str, need_s: float, body):
+        """Run `body` if every rank has `need_s` seconds of budget left; record what happened otherwise.  Rank-symmetric."""
+        if min_over_ranks(left()) < need_s:
+            return {"skipped": f"budget: fewer than {need_s:.0f} s left"}
+        stage(name)
+        t0 = time.time()
+        try:
+            res = body()
+        except lbm.LbmError as e:
+            res = {"error": str(e)}
+        if isinstance(res, dict):
+            res["seconds"] = round(time.time() - t0, 1)
+        return res
+
+    def variant(mode: str, step_allreduce: bool):
+        def body():
+            if mode == "rccl" and shared_gpu:
+                return {"error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"}
+            vs, note = set_up(params, obstacles, mode, step_allreduce, args.warmup, flags)
+            if vs is None:
+                return {"error": note}
+            vt, vav = timed(vs, args.steps, args.reps)
+            done = args.warmup + args.steps * max(1, args.reps)
+            res = {"value": nx * ny * args.steps / float(np.median(vt)) / 1e6, "unit": "MLUPS", "ms_per_step": float(np.median(vt)) / args.steps * 1e3,
+                   "ms_per_rep": [t * 1e3 for t in vt], **{k2: v for k2, v in vs.describe().items() if k2 in ("loop", "macro_k", "rccl_nranks", "step_allreduce")}}
+            if verify_on:
+                good, same, av_err = check_against_single_gpu(vs, params, obstacles, vav, done)
+                res["parity_ok"] = agree(good)
+            vs.close()
+            return res
+        return body
+
+    if partitioned and not args.no_variants:
+        variants = {}
+        for name, mode, sar in (("p2p", "p2p", False), ("rccl", "rccl", False), ("rccl_step_allreduce", "rccl", True)):
+            if (what["loop"], what["step_allreduce"]) == (mode, sar):
+                continue                                   # that is the headline
+            variants[name] = optional_part(f"variant: {name}", 45.0, variant(mode, sar))
+            if rank == 0:
+                out["variants"] = variants
+                bank(out)
+
+    # ---- BASELINE.json config 4: the shipped 1024x1024 deck on the same ranks ------------------------------------------
+    def secondary_1024():
+        digests = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))["1024x1024"]
+        p4 = lbm.read_params(os.path.join(DECKS, digests["params"]))
+        o4, _ = lbm.read_obstacles(os.path.join(DECKS, digests["obstacles"]), p4.nx, p4.ny)
+        n4 = args.secondary_steps if args.secondary_steps > 0 else p4.max_iters
+        res = {"deck": "input_1024x1024.params + obstacles_1024x1024.dat (tests/golden/decks: the reference's own files)", "steps": n4,
+               "reference_published_s": 5.90364, "reference_published_note": "d2q9-bgk_best.out:8-12, 64 MPI ranks on 4 x 16 Xeon E5-2670 cores, 20 000 steps"}
+        for mode in ("p2p", "rccl"):
+            if mode == "rccl" and shared_gpu:
+                res[mode] = {"error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"}
+                continue
+            s4, note = set_up(p4, o4, mode, False, 0, flags)
+            if s4 is None:
+                res[mode] = {"error": note}
+                continue
+            t4, av4 = timed(s4, n4, 1)
+            r4 = {"seconds": t4[0], "us_per_step": t4[0] / n4 * 1e6, "value": p4.nx * p4.ny * n4 / t4[0] / 1e6, "unit": "MLUPS",
+                  **{k2: v for k2, v in s4.describe().items() if k2 in ("loop", "macro_k", "p2p", "rccl_nranks")}}
+            if verify_on:
+                good, same, av_err = check_against_single_gpu(s4, p4, o4, av4, n4)
+                r4["parity_ok"] = agree(good)
+            if n4 == p4.max_iters:                         # the whole deck: the reference binary's own Reynolds line and av_vels
+                re_line = s4.reynolds()
+                if rank == 0:
+                    r4["reynolds_line_equals_reference"] = ("Reynolds number:\t\t%.12E" % re_line) == digests["reynolds_line"]
+                    idx = np.asarray(digests["av_sample_steps"])
+                    r4["av_vels_max_rel_to_reference_samples"] = float(np.max(np.abs(av4[idx] - np.asarray(digests["av_sample_values"])) /
+                                                                               np.asarray(digests["av_sample_values"])))
+            s4.close()
+            res[mode] = r4
+        return res
+
+    if partitioned and not args.no_secondary:
+        sec = optional_part("secondary: input_1024x1024", 40.0, secondary_1024)
+        if rank == 0:
+            out["secondary"] = {"input_1024x1024": sec}
+            bank(out)
+
+    if rank == 0:
+        if world == 1 and not args.ring and not args.no_cpu_baseline:
+            stage("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(lbm, params, obstacles, args.cpu_seconds)
+        out["wall_s"] = round(time.time() - t_start, 1)
         emit(out)
+    stage("tear-down")
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:               # noqa: BLE001 - the line is out; a rank that is gone changes nothing
+            pass
     return 0
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 2
+#define LBM_ABI_VERSION 3
 #define LBM_NSPEEDS 9               /* d2q9-bgk.c:62 */
 
 /* Run constants as read from the parameter file: t_param (d2q9-bgk.c:79-90) minus free_cells_inv,
@@ -106,7 +106,8 @@ int lbm_create_global(lbm_ctx** ctx, const lbm_params* p, int free_cells, const 
 typedef struct lbm_layout {
   int y0, ny_local;                 /* rows [y0, y0+ny_local) of the global grid belong to the rank */
   int macro_k;                      /* K of K-step mode for the whole run, or 0 */
-  int ghost;                        /* obstacle rows to supply below and above the owned rows (= macro_k) */
+  int ghost;                        /* rows kept (and obstacle rows to supply) below and above the owned rows: macro_k, or 4 at
+                                       macro_k = 3 so that a step count 3 does not divide ends in 3s and 4s (LBM_TUNE_MACRO_GHOST) */
 } lbm_layout;
 int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, lbm_layout* out);
 
@@ -175,10 +176,12 @@ int    lbm_step_boundary(lbm_ctx* ctx, void* stream);
 int    lbm_step_finish(lbm_ctx* ctx, void* stream);
 /* ---- K-step stepping of a row-partitioned run (contexts from lbm_create_global) ------------------
  *
- * One macro-step = min(K, steps left) iterations of d2q9-bgk.c:315-378 with ONE halo exchange:
+ * One macro-step = lbm_macro_next_steps() iterations of d2q9-bgk.c:315-378 with ONE halo exchange — K of them, fewer
+ * at the end of a run, and where the partition keeps four ghost rows at K = 3 a step count that 3 does not divide is
+ * split into 3s and 4s; the sequence depends on (K, ghost rows, steps left) only, so every rank makes the same one:
  *     [caller: for each of the 9 planes, send lbm_macro_send_ptr(dir, plane) to the neighbour in
  *      direction dir and receive lbm_macro_recv_ptr(dir, plane) from it: lbm_macro_halo_floats()
- *      floats = K whole rows each; the pointers refer to the CURRENT grid and change every macro-step]
+ *      floats = `ghost` whole rows each; the pointers refer to the CURRENT grid and change every macro-step]
  *     lbm_macro_interior(ctx, stream)   tiles that need no ghost row, overlaps the exchange
  *     [exchange complete]
  *     lbm_macro_edge(ctx, stream)       first and last tile row
@@ -188,6 +191,7 @@ int    lbm_step_finish(lbm_ctx* ctx, void* stream);
  * lbm_macro_exchange_local(): the exchange between two contexts of one process (device copies):
  * src's rows travelling in direction dir become dst's ghost rows. */
 int    lbm_macro_steps(const lbm_ctx* ctx);
+int    lbm_macro_next_steps(const lbm_ctx* ctx);   /* steps of the macro-step about to be made (0: no run in progress) */
 size_t lbm_macro_halo_floats(const lbm_ctx* ctx);
 void*  lbm_macro_send_ptr(lbm_ctx* ctx, int dir, int plane);
 void*  lbm_macro_recv_ptr(lbm_ctx* ctx, int dir, int plane);
@@ -224,6 +228,15 @@ void*  lbm_step_sums_device_ptr(lbm_ctx* ctx);
  * *ms = time from just before the first step kernel to just after the last one, *launches = the
  * number of step-kernel launches in between.  Valid once that stream has been synchronised. */
 int lbm_last_run_kernel_ms(lbm_ctx* ctx, double* ms, int* launches);
+
+/* Per-launch timing of lbm_run — what the measurement harness divides the per-launch HBM bytes by (the reference's
+ * profiling region is MPI_Pcontrol(1/-1, "mainloop"), d2q9-bgk.c:275-277,404-406).  lbm_set_profile(ctx, 1): every later
+ * lbm_run brackets each step-kernel launch with HIP timing events on its stream (a profiled run is for the breakdown:
+ * the events cost a few microseconds per launch).  lbm_launch_profile: the last profiled run's launches in order —
+ * steps[i] = lattice steps launch i advanced (lbm_multi_kernel<K>: K), us[i] = its duration; *n_launches = how many
+ * there were (at most `cap` are written). */
+int lbm_set_profile(lbm_ctx* ctx, int on);
+int lbm_launch_profile(lbm_ctx* ctx, int cap, int* steps, double* us, int* n_launches);
 
 /* The context's HIP device ordinal and its own stream (a hipStream_t as void*): what NULL means
  * for the `stream` arguments above. */

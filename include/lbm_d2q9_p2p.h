@@ -7,7 +7,8 @@
  * the end-of-run MPI_Reduce (:396) — without a communication library on the path:
  *
  *   - every rank maps its two ring neighbours' grids (hipIpcOpenMemHandle across processes, plain peer
- *     access inside one process) and, once per K steps, a small kernel stores its first / last K rows
+ *     access inside one process) and, once per macro-step of k steps (lbm_macro_next_steps: K, or 3s and 4s), a
+ *     small kernel stores its first / last k rows
  *     straight into the neighbours' ghost rows (system-scope stores over the direct xGMI link), then
  *     raises an epoch flag in the neighbour's exported window (release, system scope);
  *   - the consumer's edge launch is preceded on its stream by a one-wave kernel that spins on the two
@@ -56,8 +57,35 @@ int lbm_p2p_destroy(lbm_p2p* t);
 /* n_steps iterations of d2q9-bgk.c:315-378 for this rank, then the reduction of :396: tot_u_per_step (host,
  * n_steps doubles) receives the GLOBAL per-step sum of |u|, bitwise identical on every rank;
  * av_vels[tt] = tot_u_per_step[tt] * free_cells_inv (:367).  Returns after the device work has completed;
- * non-zero if a neighbour's rows did not arrive within the time-out (LBM_P2P_TIMEOUT_MS, default 30 000). */
+ * non-zero if a neighbour's rows did not arrive within the time-out (LBM_P2P_TIMEOUT_MS, default 30 000): the
+ * time-out bounds how far apart the ranks may ENTER a run (rank skew — a rank busy writing a multi-GB file while
+ * the others start the next run), not only how long a failed peer is waited for.  After such an error the transport
+ * is unusable (the neighbours' epochs no longer agree): every later lbm_p2p_run fails at once; destroy and re-create. */
 int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step);
+
+/* Where a run's time goes — the counterpart of the reference's profiling region around its main loop
+ * (MPI_Pcontrol(1/-1, "mainloop"), d2q9-bgk.c:275-277,404-406).  With the profile switched on, lbm_p2p_run brackets its
+ * launches with HIP events on the streams they run on (which perturbs the schedule by a few per cent: a profiled run is
+ * for the breakdown, not for the headline time) and lbm_p2p_phases returns, in microseconds unless named otherwise:
+ *    0 host_total          wall time of the lbm_p2p_run call
+ *    1 host_enqueue        ... of which until the last launch was enqueued
+ *    2 device_span         first event of the run -> end of the reduction, on the device
+ *    3 setup               start of the run -> just before the first step kernel (counter reset, step-0 accelerate_flow)
+ *    4 steps               first step kernel -> last step kernel done
+ *    5 reduce              last step kernel done -> global sums in host memory (fold + all-gather + sum)
+ *    6 macro_steps         COUNT of macro-steps (launch pairs) of the run
+ *    7 macro_step_avg      steps / macro_steps
+ *    8 macro_step_steady   the same without the first and the last macro-step (0 with fewer than three)
+ *    9 interior_avg        average duration of the interior launches (serial schedule: the one launch over all tiles)
+ *   10 edge_avg            ... of the edge launches (0 in the serial schedule)
+ *   11 push_first          the push + wait kernel before the first macro-step
+ *   12 push_avg            the later push + wait kernels (each includes waiting for both neighbours' rows)
+ *   13 host_overhead       host_total - device_span: launch latency before the first event + wake-up after the last
+ * One-step mode fills 0-7 only.  lbm_p2p_phase_name(i) returns the names above (NULL past the last). */
+#define LBM_P2P_PHASES 16
+int lbm_p2p_set_profile(lbm_p2p* t, int on);
+int lbm_p2p_phases(const lbm_p2p* t, double* values /* LBM_P2P_PHASES */);
+const char* lbm_p2p_phase_name(int i);
 
 /* Facts for logs and the measurement harness: how the exported window was allocated ("uncached",
  * "fine-grained" or "coarse"), how the neighbours are reached ("ipc", "in-process" or "self"), and the

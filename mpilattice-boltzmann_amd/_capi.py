@@ -13,7 +13,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NSPEEDS = 9
 
 FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP, FLAG_FAST_AVVELS = 0, 1, 2, 4, 8, 16, 32, 64
@@ -64,6 +64,7 @@ _SIGNATURES = {
     "lbm_step_boundary": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_step_finish": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_steps": (C.c_int, [_ctx]),
+    "lbm_macro_next_steps": (C.c_int, [_ctx]),
     "lbm_macro_halo_floats": (C.c_size_t, [_ctx]),
     "lbm_macro_send_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
     "lbm_macro_recv_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "lbm_step_collect": (C.c_int, [_ctx, C.c_void_p, _P(C.c_double), C.c_int]),
     "lbm_step_sums_device_ptr": (C.c_void_p, [_ctx]),
     "lbm_last_run_kernel_ms": (C.c_int, [_ctx, _P(C.c_double), _P(C.c_int)]),
+    "lbm_set_profile": (C.c_int, [_ctx, C.c_int]),
+    "lbm_launch_profile": (C.c_int, [_ctx, C.c_int, _P(C.c_int), _P(C.c_double), _P(C.c_int)]),
     "lbm_device": (C.c_int, [_ctx]),
     "lbm_stream": (C.c_void_p, [_ctx]),
     "lbm_describe": (C.c_int, [_ctx, C.c_char_p, C.c_size_t, _P(C.c_longlong), _P(C.c_longlong)]),
@@ -102,7 +105,11 @@ _P2P_SIGNATURES = {
     "lbm_p2p_destroy": (C.c_int, [C.c_void_p]),
     "lbm_p2p_run": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
     "lbm_p2p_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "lbm_p2p_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "lbm_p2p_phases": (C.c_int, [C.c_void_p, _P(C.c_double)]),
+    "lbm_p2p_phase_name": (C.c_char_p, [C.c_int]),
 }
+P2P_PHASES = 16
 P2P_EXPORTS = tuple(_P2P_SIGNATURES)
 
 _RCCL_SIGNATURES = {

@@ -83,16 +83,24 @@ __global__ void lbm_soa_to_aos_kernel(const float* grid, float* aos, size_t ps, 
 }
 
 // Outgoing halo rows of the CURRENT grid (before the first step of a row-partitioned run).
-__global__ void lbm_pack_halo_kernel(const float* grid, size_t ps, int nx, int nyl, int nxp, float* send_south, float* send_north)
+// release: the send buffers are a peer's memory (one-step peer-to-peer loop) — every block ends with the same
+// per-block system-scope release as the boundary step kernels (StepArgs::release_sends), so that the flag the
+// one-wave signal kernel raises next cannot overtake rows still sitting in another XCD's L2.
+__global__ void lbm_pack_halo_kernel(const float* grid, size_t ps, int nx, int nyl, int nxp, float* send_south, float* send_north, int release)
 {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= nx) return;
-  const float* first = grid + x;
-  const float* last = grid + static_cast<size_t>(nyl - 1) * nx + x;
-  float* ss = send_south + kHaloGuard + x;
-  float* sn = send_north + kHaloGuard + x;
-  ss[0] = first[4 * ps]; ss[nxp] = first[7 * ps]; ss[2 * nxp] = first[8 * ps];
-  sn[0] = last[2 * ps];  sn[nxp] = last[5 * ps];  sn[2 * nxp] = last[6 * ps];
+  if (x < nx) {
+    const float* first = grid + x;
+    const float* last = grid + static_cast<size_t>(nyl - 1) * nx + x;
+    float* ss = send_south + kHaloGuard + x;
+    float* sn = send_north + kHaloGuard + x;
+    ss[0] = first[4 * ps]; ss[nxp] = first[7 * ps]; ss[2 * nxp] = first[8 * ps];
+    sn[0] = last[2 * ps];  sn[nxp] = last[5 * ps];  sn[2 * nxp] = last[6 * ps];
+  }
+  if (release) {
+    __syncthreads();                                             // every wave's stores have left the CU
+    if (threadIdx.x == 0) __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope: this XCD's L2 written back
+  }
 }
 
 // K-step row partitions: gather the K first / last owned rows of all 9 planes into one contiguous

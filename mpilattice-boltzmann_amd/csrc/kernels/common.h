@@ -1,6 +1,7 @@
 // common.h — constants, argument block of the one-step kernels, loads/stores, reductions, the cell arithmetic (relax_cell), source-row selection
 // Part of the single translation unit lbm_kernels.hip (device code of liblbm_d2q9.so, gfx950 only).
 #pragma once
+#include "exact_math.h"      // f2, recip_exact, sqrt_of_float: the shortened exact sequences, enumerated by scripts/experiments/*_exhaustive.hip
 
 namespace {
 
@@ -174,25 +175,6 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 d
 // fold's latency (a dependent load + two barriers) is off the critical path of the tiny grids.
 __device__ __forceinline__ void fold_previous(const StepArgs& a, double* red);
 
-// sqrt((double)x) for a float x (d2q9-bgk.c:667 promotes u_sq to double), correctly rounded.  hipcc's sqrt(double) is
-// v_rsq_f64, one joint refinement of g ~ sqrt(x) and h ~ 1/(2 sqrt(x)), two Newton corrections of g and a rescaling of
-// arguments below 2^-767: 11 + 5 instructions.  A converted float is never that small, and for a 24-bit significand the
-// refinement is not needed: the raw estimates followed by two corrections already give the correctly rounded result for
-// EVERY non-negative float — 2 139 095 041 values enumerated on gfx950, scripts/experiments/sqrt_exhaustive.hip (one
-// correction after the refinement would do as well; one correction alone is wrong for half of them).  7 instructions.
-__device__ __forceinline__ double sqrt_of_float(float xf)
-{
-  const double x = static_cast<double>(xf);
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  const double h = y * 0.5;
-  double d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  return __builtin_amdgcn_class(x, 0x260) ? x : g;     // +-0 and +inf map to themselves
-}
-
 // One cell (T = float) or an x-pair of cells (T = f2, packed v_pk_*_f32): moments, equilibrium and
 // relaxation (d2q9-bgk.c:546-666).  Every value is produced by the reference's own sequence of
 // roundings; two things differ in form only:
@@ -204,43 +186,10 @@ __device__ __forceinline__ double sqrt_of_float(float xf)
 //     instruction and a consumer of its result, which hipcc fills with s_nop (4 cycles, as much as
 //     the instruction itself) when the next instruction in program order is that consumer.
 // msq = m^2 (un-normalised momentum squared), rinv = 1/rho.
-typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ float splat_as(float, float v) { return v; }
 __device__ __forceinline__ f2 splat_as(f2, float v) { return f2{v, v}; }
-// 1.0f / x, correctly rounded (:561).  hipcc's division is twelve instructions (two div_scale, rcp, six fma, div_fmas,
-// div_fixup).  v_rcp_f32 and ONE Newton step give the same bits whenever the magnitude of their result is at least
-// 2^-126 (i.e. the result is a normal number; a NaN fails the comparison): checked against the division on all 2^32 bit
-// patterns on gfx950 (scripts/experiments/recip_exhaustive.hip) — so the test is one compare on the result, and a wave
-// that holds anything else (x zero, denormal, above 2^126, infinite or NaN) takes the division.
-#ifndef LBM_RECIP_DIVISION
-#define LBM_RECIP_DIVISION 0          // 1: timing / cross-check builds that always divide
-#endif
-__device__ __forceinline__ float recip_newton(float x)
-{
-  const float r = __builtin_amdgcn_rcpf(x);
-  const float e = __builtin_fmaf(-x, r, 1.0f);
-  return __builtin_fmaf(e, r, r);
-}
-__device__ __forceinline__ float recip_exact(float x)
-{
-  if (LBM_RECIP_DIVISION) return 1.0f / x;
-  const float q = recip_newton(x);
-  if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(q) >= 0x1p-126f) == __builtin_amdgcn_read_exec()) return q;
-  return 1.0f / x;
-}
-__device__ __forceinline__ f2 recip_exact(f2 x)
-{
-  f2 r;
-  if (LBM_RECIP_DIVISION) { r.x = 1.0f / x.x; r.y = 1.0f / x.y; return r; }
-  r.x = recip_newton(x.x); r.y = recip_newton(x.y);
-  const unsigned long long ok = __builtin_amdgcn_ballot_w64(__builtin_fabsf(r.x) >= 0x1p-126f) & __builtin_amdgcn_ballot_w64(__builtin_fabsf(r.y) >= 0x1p-126f);
-  if (ok == __builtin_amdgcn_read_exec()) return r;
-  r.x = 1.0f / x.x; r.y = 1.0f / x.y;
-  return r;
-}
-
 template <typename T>
 __device__ __forceinline__ void relax_core(const T (&t)[9], float omega, T (&o)[9], T& msq_out, T& rinv_out)
 {

@@ -147,6 +147,12 @@ struct lbm_ctx {
   int tile_single_max = 0;       // sub-steps with regions of at most this many cells deal one cell per lane
   int n_tiles = 0;
   float accel_w1 = 0.f, accel_w2 = 0.f;
+  // lbm_set_profile: timing events around every step-kernel launch of lbm_run (pool grown on demand, reused)
+  bool profile = false;
+  std::vector<hipEvent_t> prof_pool;
+  size_t prof_used = 0;
+  struct ProfLaunch { int steps; hipEvent_t begin, end; };
+  std::vector<ProfLaunch> prof_launches;
 };
 
 namespace {
@@ -300,6 +306,20 @@ void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a, bool fast)
   }
 }
 
+// Profile mode of lbm_run (lbm_set_profile): a pooled timing event recorded on `s`; nullptr when off.
+hipEvent_t prof_stamp(lbm_ctx* c, hipStream_t s)
+{
+  if (!c->profile) return nullptr;
+  if (c->prof_used == c->prof_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->prof_pool.push_back(e);
+  }
+  hipEvent_t e = c->prof_pool[c->prof_used++];
+  if (hipEventRecord(e, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+
 int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
 {
   if (ensure_sums(c, n_steps)) return 1;
@@ -338,6 +358,18 @@ int fold_last(lbm_ctx* c, hipStream_t s)
   c->n_prev = 0;
   c->n_prev_vecs = 1;
   return 0;
+}
+
+// Steps of the next launch of lbm_multi_kernel when `left` steps remain: multi_K, except that at K = 3 a count that 3
+// does not divide is split into 3s and 4s where that avoids a K = 2 / K = 1 launch at the end — whole periodic grids
+// (the frame wraps) and row partitions that keep four ghost rows.  A function of (K, ghost, left) only, so every rank of
+// a partitioned run makes the same sequence of macro-steps.
+int next_multi_k(const lbm_ctx* c, int left)
+{
+  int k = std::min(c->multi_K, left);
+  const bool room = c->self_periodic || c->ghost >= 4;
+  if (c->multi_K == 3 && room && c->multi_tail4 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
+  return k;
 }
 
 constexpr int kGraphSteps = 64;   // even: the source/destination roles and the partial-sum parity return to their start
@@ -399,6 +431,17 @@ static int macro_k_for(size_t max_cells)
   return std::min(std::max(tune_env("LBM_TUNE_MACRO_K", by_size), 0), kMaxMultiSteps);
 }
 
+// Ghost rows kept on each side of a K-step partition.  One more than K at K = 3: a run whose step count 3 does not
+// divide then ends in 3s and 4s like lbm_run's (a K = 2 macro-step costs 140 us where two thirds of a K = 3 one
+// would be 98, on 8192 x 1024 rows), and a 4-step launch only needs the fourth row to be there.  The exchange
+// moves the rows the NEXT macro-step needs (peer-to-peer loop) or all `ghost` rows (RCCL loop).
+static int macro_ghost_for(int k)
+{
+  if (k <= 0) return 0;
+  const int by_k = k == 3 ? 4 : k;
+  return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_k), k), kMaxMultiSteps);
+}
+
 // Tile width of lbm_multi_kernel by partition size: 64 x 16 tiles for the bandwidth-bound grids; 32 x 16 where 64 x 16
 // tiles would not even fill the chip once (256 CUs x 3 blocks), so that the launch is bound by one block's chain of
 // sub-steps: half the work per block, twice the blocks.  Measured us/step for 64 / 32 wide tiles (K = 3, one GPU):
@@ -448,7 +491,7 @@ static void pack_obstacle_bits(std::vector<uint32_t>& bits, int rows, int nx, Ro
 // rows possible.  forced_k < 0: K-step mode and K decided from this partition's own shape
 // (lbm_create_global); >= 0: decided by the caller for the whole run (lbm_rank_layout).
 static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows,
-                       const int* obstacles_global, const int* obstacles_window, int forced_k, int y0, int ny_local,
+                       const int* obstacles_global, const int* obstacles_window, int forced_k, int forced_ghost, int y0, int ny_local,
                        int device, unsigned flags)
 {
   if (!out || !p || !obstacles_rows) { lbm_internal::set_error("lbm_create: null argument"); return 1; }
@@ -483,16 +526,18 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
   const bool fits_u32 = static_cast<size_t>(p->nx) * (ny_local + 2 * kMaxMultiSteps) < (size_t(1) << 30);
   if (forced_k > 0) {
-    if (self_periodic || !obstacles_window || forced_k > kMaxMultiSteps || !macro_eligible(p, ny_local, flags)) {
+    if (self_periodic || !obstacles_window || forced_k > kMaxMultiSteps || forced_ghost < forced_k || forced_ghost > kMaxMultiSteps ||
+        !macro_eligible(p, ny_local, flags)) {
       lbm_internal::set_error("lbm_create_rank: partition cannot run the K-step mode its layout asks for");
       delete c;
       return 1;
     }
-    c->multi_K = forced_k; c->ghost = forced_k;
+    c->multi_K = forced_k; c->ghost = forced_ghost;
   } else if (forced_k < 0 && !self_periodic && obstacles_global && macro_eligible(p, ny_local, flags)) {
     const int k = macro_k_for(c->ncells);
-    if (k > 0) { c->multi_K = k; c->ghost = k; }
+    if (k > 0) { c->multi_K = k; c->ghost = macro_ghost_for(k); }
   }
+  c->multi_tail4 = tune_env("LBM_TUNE_MULTI_TAIL4", 1) != 0;
   c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
   c->ps = plane_stride_floats(c->ncells_storage);
   c->grid_floats = 9 * c->ps + 128;
@@ -599,7 +644,6 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     //   1024x1024 11.2 / 8.3 / 8.5 (13.5)   512x512 3.7 / 3.4 / 3.3 (6.3; lbm_tile_kernel 5.2)
     // K = 2 is HBM-bound, K = 4 instruction-bound at 2 blocks per CU (60 KB frames); K = 3 sits at both limits
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 3), 0), kMaxMultiSteps);
-    c->multi_tail4 = tune_env("LBM_TUNE_MULTI_TAIL4", 1) != 0;
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
@@ -636,14 +680,14 @@ extern "C" {
 int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows, int y0,
                int ny_local, int device, unsigned flags)
 {
-  return create_impl(out, p, free_cells, obstacles_rows, nullptr, nullptr, 0, y0, ny_local, device, flags);
+  return create_impl(out, p, free_cells, obstacles_rows, nullptr, nullptr, 0, 0, y0, ny_local, device, flags);
 }
 
 int lbm_create_global(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_all, int y0,
                       int ny_local, int device, unsigned flags)
 {
   if (!obstacles_all || !p || y0 < 0) { lbm_internal::set_error("lbm_create_global: bad argument"); return 1; }
-  return create_impl(out, p, free_cells, obstacles_all + static_cast<size_t>(y0) * p->nx, obstacles_all, nullptr, -1, y0, ny_local, device, flags);
+  return create_impl(out, p, free_cells, obstacles_all + static_cast<size_t>(y0) * p->nx, obstacles_all, nullptr, -1, 0, y0, ny_local, device, flags);
 }
 
 // One mode and one K for every rank of a run, from global quantities only (see the header).
@@ -661,7 +705,7 @@ int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, l
   const bool partitioned = nranks > 1 || (flags & LBM_FLAG_FORCE_HALO);
   if (partitioned && macro_eligible(p, lo, flags) && macro_eligible(p, hi, flags))
     out->macro_k = macro_k_for(static_cast<size_t>(p->nx) * hi);
-  out->ghost = out->macro_k;
+  out->ghost = macro_ghost_for(out->macro_k);
   return 0;
 }
 
@@ -672,7 +716,7 @@ int lbm_create_rank(lbm_ctx** out, const lbm_params* p, int free_cells, const in
   if (!obstacle_window) { lbm_internal::set_error("lbm_create_rank: null argument"); return 1; }
   if (lbm_rank_layout(p, nranks, rank, flags, &lay)) return 1;
   const int* rows = obstacle_window + static_cast<size_t>(lay.ghost) * p->nx;          // the owned rows inside the window
-  return create_impl(out, p, free_cells, rows, nullptr, obstacle_window, lay.macro_k, lay.y0, lay.ny_local, device, flags);
+  return create_impl(out, p, free_cells, rows, nullptr, obstacle_window, lay.macro_k, lay.ghost, lay.y0, lay.ny_local, device, flags);
 }
 
 int lbm_destroy(lbm_ctx* c)
@@ -692,6 +736,7 @@ int lbm_destroy(lbm_ctx* c)
   if (c->counter) (void)hipFree(c->counter);
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+  for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -705,18 +750,20 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   if (n_steps == 0) return 0;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
+  c->prof_used = 0;
+  c->prof_launches.clear();
   if (begin_run(c, n_steps, s)) return 1;
   int tile_launches = 0;
   const bool multi = c->multi_K > 0 && c->self_periodic;
   for (int t = 0; multi && t < n_steps;) {
     // up to multi_K steps per pass over HBM (lbm_multi_kernel).  A step count that 3 does not divide is split into 3s
     // and 4s where that avoids the K = 2 / K = 1 launch at the end (8192 x 8192, us per launch: K = 1 870, K = 2 1000,
-    // K = 3 1050, K = 4 1460): n = 3a + 4 for n mod 3 = 1, n = 3a + 8 for n mod 3 = 2.  Whole periodic grids only — a
-    // row partition has K ghost rows, not four.
-    const int left = n_steps - t;
-    int k = std::min(c->multi_K, left);
-    if (c->multi_K == 3 && c->multi_tail4 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
+    // K = 3 1050, K = 4 1460): n = 3a + 4 for n mod 3 = 1, n = 3a + 8 for n mod 3 = 2 (next_multi_k; row partitions
+    // with four ghost rows split the same way).
+    const int k = next_multi_k(c, n_steps - t);
+    hipEvent_t pb = prof_stamp(c, s);
     launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, c->multi_tiles, 0, 0, /*fold=*/true, s);
+    if (c->profile) c->prof_launches.push_back({k, pb, prof_stamp(c, s)});
     c->n_prev = c->multi_tiles; c->n_prev_vecs = k;
     c->parity ^= 1;
     c->cur ^= 1;
@@ -739,10 +786,12 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     a.n_prev = c->n_prev; a.n_prev_vecs = c->n_prev > 0 ? c->n_prev_vecs : 0;
     a.sums = c->sums; a.counter = c->counter;
     const dim3 grid(c->n_tiles + 1);
+    hipEvent_t pb = prof_stamp(c, s);
     if (c->tile_T == 16 && c->tile_H == 8) launch_tile<16, 8>(grid, s, a, c->fast_avvels);
     else if (c->tile_T == 16) launch_tile<16, 4>(grid, s, a, c->fast_avvels);
     else if (c->tile_H == 8) launch_tile<8, 8>(grid, s, a, c->fast_avvels);
     else launch_tile<8, 4>(grid, s, a, c->fast_avvels);
+    if (c->profile) c->prof_launches.push_back({k, pb, prof_stamp(c, s)});
     ++tile_launches;
     c->n_prev = c->n_tiles; c->n_prev_vecs = k;
     c->parity ^= 1;
@@ -758,7 +807,9 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
       HIP_TRY(hipGraphLaunch(c->graph_exec[c->cur], s));
       t += kGraphSteps;
     } else {
+      hipEvent_t pb = prof_stamp(c, s);
       full_step(c, /*accel_next=*/t + 1 < n_steps, s);
+      if (c->profile) c->prof_launches.push_back({1, pb, prof_stamp(c, s)});
       t += 1;
     }
   }
@@ -913,7 +964,7 @@ int lbm_step_prepare(lbm_ctx* c, int n_steps, void* stream)
   if (begin_run(c, n_steps, s)) return 1;
   const int nx = c->p.nx;
   hipLaunchKernelGGL(lbm_pack_halo_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps, nx, c->nyl, c->nxp,
-                     c->send[0], c->send[1]);
+                     c->send[0], c->send[1], c->release_sends ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1044,17 +1095,19 @@ int lbm_macro_prepare(lbm_ctx* c, int n_steps, void* stream)
   return begin_run(c, n_steps, pick_stream(c, stream));
 }
 
-static int macro_k(const lbm_ctx* c) { return std::min(c->multi_K, c->run_steps - c->run_done); }
+static int macro_k(const lbm_ctx* c) { return next_multi_k(c, c->run_steps - c->run_done); }
+
+int lbm_macro_next_steps(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run_done < c->run_steps) ? macro_k(c) : 0; }
 
 // Tile rows of a K-step partition: row 0 and the top `top_edge_rows` rows read ghost rows (edge launch,
 // after the exchange); the `interior_rows` rows between them do not.  The top edge is two tile rows
-// when the last one holds fewer than K owned rows (the ring of the row below then reaches the ghosts).
+// when the last one holds fewer owned rows than a launch makes steps (the ring of the row below then reaches the ghosts).
 struct MacroRows { int interior_rows, top_edge_rows; };
 static MacroRows macro_rows(const lbm_ctx* c)
 {
   const int nty = (c->nyl + kMTY - 1) / kMTY;
   const int last_rows = c->nyl - (nty - 1) * kMTY;
-  int top = last_rows < c->multi_K ? 2 : 1;
+  int top = last_rows < c->ghost ? 2 : 1;                  // (ghost = the most steps a launch of this partition makes)
   top = std::min(top, nty - 1);
   return {nty - 1 - top, top};
 }
@@ -1148,6 +1201,32 @@ int lbm_last_run_kernel_ms(lbm_ctx* c, double* ms, int* launches)
   HIP_TRY(hipEventElapsedTime(&t, c->ev_begin, c->ev_end));
   *ms = t;
   if (launches) *launches = c->ev_launches;
+  return 0;
+}
+
+int lbm_set_profile(lbm_ctx* c, int on)
+{
+  if (!c) { lbm_internal::set_error("lbm_set_profile: null context"); return 1; }
+  c->profile = on != 0;
+  if (!c->profile) c->prof_launches.clear();
+  return 0;
+}
+
+int lbm_launch_profile(lbm_ctx* c, int cap, int* steps, double* us, int* n_launches)
+{
+  if (!c || !n_launches || cap < 0 || (cap > 0 && (!steps || !us))) { lbm_internal::set_error("lbm_launch_profile: bad argument"); return 1; }
+  HIP_TRY(hipSetDevice(c->device));
+  *n_launches = static_cast<int>(c->prof_launches.size());
+  const int n = std::min(cap, *n_launches);
+  for (int i = 0; i < n; ++i) {
+    const lbm_ctx::ProfLaunch& l = c->prof_launches[i];
+    float ms = 0.f;
+    if (!l.begin || !l.end) { lbm_internal::set_error("lbm_launch_profile: a timing event could not be recorded"); return 1; }
+    HIP_TRY(hipEventSynchronize(l.end));
+    HIP_TRY(hipEventElapsedTime(&ms, l.begin, l.end));
+    steps[i] = l.steps;
+    us[i] = static_cast<double>(ms) * 1e3;
+  }
   return 0;
 }
 

@@ -2,7 +2,7 @@
 // Included at the end of lbm_kernels.hip: it drives the K-step launches of a context directly
 // (launch_multi, begin_run, fold_last) and owns the streams / events / mapped peer memory of one rank.
 //
-// Per macro-step (K steps) of one rank, reference lines d2q9-bgk.c:
+// Per macro-step (k steps: K, or 3s and 4s — next_multi_k) of one rank, reference lines d2q9-bgk.c:
 //
 //   compute stream                    edge stream
 //   ──────────────                    ───────────
@@ -21,6 +21,8 @@
 #pragma once
 
 #include <unistd.h>
+
+#include <chrono>
 
 #include "lbm_d2q9_p2p.h"
 
@@ -68,6 +70,12 @@ struct lbm_p2p {
   bool connected = false;
   unsigned long long epoch = 0, reduce_round = 0;
   long long timeout_ticks = 0;
+  // lbm_p2p_set_profile: timing events around the launches of a run (a pool, grown on demand and reused)
+  bool profile = false, phases_valid = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  hipEvent_t ev_reduce_end = nullptr;
+  double phases[LBM_P2P_PHASES] = {};
 };
 
 namespace {
@@ -95,25 +103,59 @@ void p2p_unmap(lbm_p2p* t)
   }
 }
 
-// The K rows of the CURRENT grid that the neighbours need, into their ghost rows of the grid with the same
-// parity, flags := epoch; then (same kernel) wait for the neighbours' rows of that epoch to have arrived here.
-int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s, bool exposed = false)
+// Profile mode: the next pooled timing event, recorded on `s` (nullptr when the profile is off or on failure).
+hipEvent_t p2p_stamp(lbm_p2p* t, hipStream_t s)
+{
+  if (!t->profile) return nullptr;
+  if (t->ev_used == t->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    t->ev_pool.push_back(e);
+  }
+  hipEvent_t e = t->ev_pool[t->ev_used++];
+  if (hipEventRecord(e, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+
+double p2p_us(hipEvent_t a, hipEvent_t b)
+{
+  float ms = 0.f;
+  if (!a || !b || hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
+  return static_cast<double>(ms) * 1e3;
+}
+
+struct P2PSpan { hipEvent_t begin = nullptr, end = nullptr; };
+
+double p2p_avg_us(const std::vector<P2PSpan>& v, size_t from = 0)
+{
+  double s = 0.0;
+  size_t n = 0;
+  for (size_t i = from; i < v.size(); ++i)
+    if (v[i].begin && v[i].end) { s += p2p_us(v[i].begin, v[i].end); ++n; }
+  return n ? s / static_cast<double>(n) : 0.0;
+}
+
+// The k rows of the CURRENT grid that each neighbour needs for its next macro-step of k steps, into the k ghost rows
+// next to its owned rows in the grid of the same parity, flags := epoch; then (same kernel) wait for the neighbours'
+// rows of that epoch to have arrived here.
+int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool exposed = false)
 {
   lbm_ctx* c = t->ctx;
   const P2PPeer& ps = t->peers[t->south];
   const P2PPeer& pn = t->peers[t->north];
-  const int K = c->ghost, nx = c->p.nx, g = c->cur;
+  const int nx = c->p.nx, g = c->cur;
   P2PPushArgs a{};
   a.src = c->grid[g];
   a.ps = c->ps;
-  // south neighbour: its top ghost rows start at storage row ghost + nyl(south); north neighbour: row 0
+  // south neighbour: the first k of its TOP ghost rows (storage row ghost + nyl of ITS layout); north neighbour: the
+  // last k of its bottom ghost rows (storage rows ghost - k .. ghost - 1)
   a.dst[0] = ps.grid_alloc[g] + 64 + static_cast<size_t>(ps.blob.ghost + ps.blob.nyl) * nx;
-  a.dst[1] = pn.grid_alloc[g] + 64;
+  a.dst[1] = pn.grid_alloc[g] + 64 + static_cast<size_t>(pn.blob.ghost - k) * nx;
   a.dst_ps[0] = ps.blob.ps;
   a.dst_ps[1] = pn.blob.ps;
-  a.src_row[0] = static_cast<size_t>(c->ghost);          // my first K owned rows
-  a.src_row[1] = static_cast<size_t>(c->nyl);            // my last K owned rows (ghost + nyl - K, ghost == K)
-  a.nfloats = K * nx;
+  a.src_row[0] = static_cast<size_t>(c->ghost);                  // my first k owned rows
+  a.src_row[1] = static_cast<size_t>(c->ghost + c->nyl - k);     // my last k owned rows
+  a.nfloats = k * nx;
   a.flag[0] = &header_of(ps.window)->halo_flag[1];       // my rows arrive from the south neighbour's NORTH
   a.flag[1] = &header_of(pn.window)->halo_flag[0];
   a.parity_word[0] = &header_of(ps.window)->halo_parity[2 * 1 + (epoch & 1ull)];
@@ -128,7 +170,7 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, hipStream_t s, bool exposed =
   const int work = 18 * (a.nfloats / 2);
   // at most 64 blocks (every block ends with an L2 write-back towards the peers), each lane moving up to four
   // float2's per pass
-  // (`exposed`: the push before the first macro-step of a run, which nothing overlaps)
+  // (`exposed`: the push before the first macro-step of a run in the serial schedule, which nothing overlaps)
   const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge : kP2PPushBlocks;
   const dim3 grid(std::max(1, std::min(max_blocks, (work + 1023) / 1024)));
   hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
@@ -158,6 +200,7 @@ int p2p_reduce(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     a.err = t->err;
     hipLaunchKernelGGL(lbm_p2p_allreduce_kernel, dim3(t->nranks), dim3(256), 0, cs, a);
     HIP_TRY(hipGetLastError());
+    t->ev_reduce_end = p2p_stamp(t, cs);
     HIP_TRY(hipStreamSynchronize(cs));
     std::memcpy(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n);     // host-mapped: the kernel wrote it in place
   }
@@ -195,7 +238,10 @@ int p2p_run_one_step(lbm_p2p* t, int n_steps, double* tot_u_per_step)
   c->release_sends = true;
   unsigned long long epoch = t->epoch + 1;
   bind(epoch, epoch);
+  const std::chrono::steady_clock::time_point h0 = std::chrono::steady_clock::now();
+  hipEvent_t e_run0 = p2p_stamp(t, cs);
   if (lbm_step_prepare(c, n_steps, cs)) return 1;              // step-0 accelerate_flow + the messages of the first step
+  hipEvent_t e_steps0 = p2p_stamp(t, cs);
   P2PWindowHeader* mine = header_of(t->window);
   for (int step = 0; step < n_steps; ++step, ++epoch) {
     hipLaunchKernelGGL(lbm_p2p_signal_wait_kernel, dim3(1), dim3(64), 0, cs, &header_of(ps.window)->halo_flag[1], &header_of(pn.window)->halo_flag[0],
@@ -203,11 +249,29 @@ int p2p_run_one_step(lbm_p2p* t, int n_steps, double* tot_u_per_step)
                        mine->halo_flag, mine->halo_parity, epoch, static_cast<unsigned long long>(c->cur), t->timeout_ticks, t->err);
     HIP_TRY(hipGetLastError());
     bind(epoch, epoch + 1);
-    if (lbm_step_interior(c, cs) || lbm_step_boundary(c, cs) || lbm_step_finish(c, cs)) return 1;
+    if (lbm_step_interior(c, cs) || lbm_step_boundary(c, cs) || lbm_step_finish(c, cs)) { (void)hipStreamSynchronize(cs); return 1; }
   }
   t->epoch = epoch - 1;
+  hipEvent_t e_steps1 = p2p_stamp(t, cs);
+  const std::chrono::steady_clock::time_point h_enq = std::chrono::steady_clock::now();
   if (p2p_reduce(t, n_steps, tot_u_per_step)) return 1;
-  return p2p_check_error(t);
+  if (p2p_check_error(t)) return 1;
+  if (t->profile) {
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    double* ph = t->phases;
+    std::fill(ph, ph + LBM_P2P_PHASES, 0.0);
+    ph[0] = us(h0, std::chrono::steady_clock::now());
+    ph[1] = us(h0, h_enq);
+    ph[2] = p2p_us(e_run0, t->ev_reduce_end);
+    ph[3] = p2p_us(e_run0, e_steps0);
+    ph[4] = p2p_us(e_steps0, e_steps1);
+    ph[5] = p2p_us(e_steps1, t->ev_reduce_end);
+    ph[6] = n_steps;
+    ph[7] = ph[4] / n_steps;
+    ph[13] = ph[0] - ph[2];
+    t->phases_valid = true;
+  }
+  return 0;
 }
 
 }  // namespace
@@ -262,10 +326,22 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   t->reduce_cap = static_cast<size_t>(std::max(ctx->p.max_iters, 4096));
   t->halo_bytes = round_up(sizeof(float) * 2 * 2 * 3 * static_cast<size_t>(ctx->nxp), 256);
   t->window_bytes = kP2PHeaderBytes + t->halo_bytes + sizeof(double) * 2 * nranks * t->reduce_cap;
+  // The protocol needs a window whose flags a running kernel sees change and whose one-step halo slots need no
+  // cache maintenance on the reader's side: uncached, or fine-grained as the fall-back.  Ordinary (coarse-grained)
+  // device memory guarantees neither — the polls could spin on a cached line — so when both allocations fail the
+  // transport is NOT created and the caller falls back to the RCCL loop.  LBM_P2P_WINDOW=2 asks for the coarse
+  // window explicitly (experiments on one GPU only).
   void* w = nullptr;
-  if (tune_env("LBM_P2P_WINDOW", 0) <= 0 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocUncached) == hipSuccess) t->window_kind = "uncached";
-  else if (tune_env("LBM_P2P_WINDOW", 0) <= 1 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocFinegrained) == hipSuccess) t->window_kind = "fine-grained";
-  else { (void)hipGetLastError(); P2P_TRY(hipMalloc(&w, t->window_bytes)); t->window_kind = "coarse"; }
+  const int want = tune_env("LBM_P2P_WINDOW", 0);
+  if (want <= 0 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocUncached) == hipSuccess) t->window_kind = "uncached";
+  else if (want <= 1 && hipExtMallocWithFlags(&w, t->window_bytes, hipDeviceMallocFinegrained) == hipSuccess) t->window_kind = "fine-grained";
+  else if (want >= 2) { (void)hipGetLastError(); P2P_TRY(hipMalloc(&w, t->window_bytes)); t->window_kind = "coarse"; }
+  else {
+    (void)hipGetLastError();
+    lbm_internal::set_error("lbm_p2p_create: neither an uncached nor a fine-grained device allocation is available for the flag window "
+                            "(hipExtMallocWithFlags failed); the peer-to-peer transport does not run on ordinary device memory");
+    return fail();
+  }
   (void)hipGetLastError();
   t->window = static_cast<char*>(w);
   P2P_TRY(hipMemset(t->window, 0, t->window_bytes));
@@ -427,6 +503,7 @@ int lbm_p2p_destroy(lbm_p2p* t)
   if (t->d_flags) (void)hipFree(t->d_flags);
   if (t->edge_done) (void)hipEventDestroy(t->edge_done);
   if (t->interior_done) (void)hipEventDestroy(t->interior_done);
+  for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
   if (t->edge) (void)hipStreamDestroy(t->edge);
   delete t;
   return 0;
@@ -434,46 +511,101 @@ int lbm_p2p_destroy(lbm_p2p* t)
 
 int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
 {
+  using clock = std::chrono::steady_clock;
   if (!t || n_steps < 0 || (n_steps > 0 && !tot_u_per_step)) { lbm_internal::set_error("lbm_p2p_run: bad argument"); return 1; }
   if (!t->connected) { lbm_internal::set_error("lbm_p2p_run: call lbm_p2p_connect first"); return 1; }
   if (n_steps == 0) return 0;
   lbm_ctx* c = t->ctx;
   HIP_TRY(hipSetDevice(c->device));
+  // the error word is sticky: after a time-out the neighbours' epochs no longer agree with this rank's, and every
+  // wait of a later run would return at once — fail here instead of stepping without the halo rows
+  if (*t->err != 0) {
+    lbm_internal::set_error("lbm_p2p_run: rank " + std::to_string(t->rank) + ": an earlier run on this transport failed [code " +
+                            std::to_string(*t->err) + "]; destroy it and create a new one");
+    return 1;
+  }
+  const clock::time_point h0 = clock::now();
+  t->ev_used = 0;
+  t->phases_valid = false;
+  t->ev_reduce_end = nullptr;
   if (c->ghost == 0) return p2p_run_one_step(t, n_steps, tot_u_per_step);
-  const int K = c->multi_K;
   hipStream_t cs = t->compute, es = t->edge_stream ? t->edge : t->compute;
-  if (begin_run(c, n_steps, cs)) return 1;                     // step-0 accelerate_flow (d2q9-bgk.c:345-348)
-  // the rows my neighbours need for the first macro-step (the state may have been set since the last run, and the
-  // step-0 accelerate_flow has just changed row ny-2).  Nothing overlaps this push: it runs right behind the accelerate
-  // kernel on the compute stream — no hop to the edge stream — with the full complement of blocks.
+  // error exits leave both streams drained: events recorded on one may be pending on the other
+  auto bail = [&]() {
+    (void)hipStreamSynchronize(cs);
+    if (t->edge_stream) (void)hipStreamSynchronize(es);
+    return 1;
+  };
+#define P2P_RUN_TRY(expr)                                                                    \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      lbm_internal::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return bail();                                                                         \
+    }                                                                                        \
+  } while (0)
+  hipEvent_t e_run0 = p2p_stamp(t, cs);
+  if (begin_run(c, n_steps, cs)) return bail();                // step-0 accelerate_flow (d2q9-bgk.c:345-348)
+  // The rows my neighbours need for the first macro-step (the state may have been set since the last run, and the
+  // step-0 accelerate_flow has just changed row ny-2).  Edge-stream schedule: the push goes to the edge stream behind
+  // the accelerate kernel and runs BESIDE interior launch 0, which reads no ghost row — only the edge launch waits
+  // for it, as in every later macro-step.  Serial schedule: right behind the accelerate kernel with the full
+  // complement of blocks (nothing overlaps it).
   unsigned long long epoch = t->epoch + 1;
-  if (p2p_push(t, epoch, cs, /*exposed=*/true)) return 1;
-  HIP_TRY(hipEventRecord(t->interior_done, cs));
-  HIP_TRY(hipEventRecord(t->edge_done, cs));
-  if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
+  std::vector<P2PSpan> sp_interior, sp_edge, sp_push;
+  {
+    const int k0 = next_multi_k(c, n_steps);
+    P2PSpan sp;
+    if (t->edge_stream) {
+      P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));       // "the accelerated state is ready"
+      P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
+      sp.begin = p2p_stamp(t, es);
+      if (p2p_push(t, epoch, k0, es)) return bail();
+      sp.end = p2p_stamp(t, es);
+    } else {
+      sp.begin = p2p_stamp(t, cs);
+      if (p2p_push(t, epoch, k0, cs, /*exposed=*/true)) return bail();
+      sp.end = p2p_stamp(t, cs);
+    }
+    sp_push.push_back(sp);
+  }
+  hipEvent_t e_steps0 = p2p_stamp(t, cs);
   const MacroRows rows = macro_rows(c);
-  for (int done = 0; done < n_steps; ++epoch) {
-    const int k = std::min(K, n_steps - done);
+  int macro_steps = 0;
+  for (int done = 0; done < n_steps; ++epoch, ++macro_steps) {
+    const int k = next_multi_k(c, n_steps - done);             // K, or 3s and 4s (the same sequence on every rank)
     const bool more = done + k < n_steps;
     if (t->edge_stream) {
       if (rows.interior_rows > 0) {                            // :350, beside the exchange
-        HIP_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+        if (macro_steps > 0) P2P_RUN_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+        P2PSpan sp;
+        sp.begin = p2p_stamp(t, cs);
         launch_multi(c, k, more, c->multi_tiles_x, c->multi_tiles_x * rows.interior_rows, 0, 0, /*fold=*/c->n_prev > 0, cs);
+        sp.end = p2p_stamp(t, cs);
+        sp_interior.push_back(sp);
         c->n_prev = 0;
       }
       // MPI_Waitall (:364) happened on the device, at the end of the push kernel that precedes this launch
-      HIP_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
+      if (macro_steps > 0) P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));   // interior m-1: sources of the edge tiles
+      P2PSpan sp;
+      sp.begin = p2p_stamp(t, es);
       launch_multi(c, k, more, 0, c->multi_tiles_x, (1 + rows.interior_rows) * c->multi_tiles_x, rows.top_edge_rows * c->multi_tiles_x,
                    /*fold=*/c->n_prev > 0, es);               // :365-366
+      sp.end = p2p_stamp(t, es);
+      sp_edge.push_back(sp);
       c->n_prev = 0;
-      HIP_TRY(hipEventRecord(t->interior_done, cs));
+      P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));
     } else {
+      P2PSpan sp;
+      sp.begin = p2p_stamp(t, cs);
       launch_multi(c, k, more, 0, c->multi_tiles, 0, 0, /*fold=*/c->n_prev > 0, cs);
+      sp.end = p2p_stamp(t, cs);
+      sp_interior.push_back(sp);
       c->n_prev = 0;
     }
-    HIP_TRY(hipGetLastError());
+    P2P_RUN_TRY(hipGetLastError());
     // the next interior launch needs this macro-step's edge ROWS, not the push that follows them
-    if (t->edge_stream) HIP_TRY(hipEventRecord(t->edge_done, es));
+    if (t->edge_stream) P2P_RUN_TRY(hipEventRecord(t->edge_done, es));
     // state flip of lbm_macro_finish (d2q9-bgk.c:376-378)
     c->n_prev = c->multi_tiles;
     c->n_prev_vecs = k;
@@ -482,20 +614,71 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     c->run_done += k;
     c->ev_tile_launches += t->edge_stream ? 2 : 1;
     done += k;
-    if (more) {
-      if (p2p_push(t, epoch + 1, es)) return 1;                // MPI_Startall (:327) for the next macro-step
+    if (more) {                                                // MPI_Startall (:327) for the next macro-step
+      P2PSpan sp;
+      sp.begin = p2p_stamp(t, es);
+      if (p2p_push(t, epoch + 1, next_multi_k(c, n_steps - done), es)) return bail();
+      sp.end = p2p_stamp(t, es);
+      sp_push.push_back(sp);
     }
   }
   t->epoch = epoch - 1;
-  if (t->edge_stream) HIP_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
-  HIP_TRY(hipEventRecord(c->ev_end, cs));
+  if (t->edge_stream) P2P_RUN_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+  P2P_RUN_TRY(hipEventRecord(c->ev_end, cs));
+  hipEvent_t e_steps1 = p2p_stamp(t, cs);
   c->ev_launches = c->ev_tile_launches;
   c->ev_valid = true;
-  if (fold_last(c, cs)) return 1;
-  if (p2p_reduce(t, n_steps, tot_u_per_step)) return 1;
-  if (t->edge_stream) HIP_TRY(hipStreamSynchronize(es));
+  if (fold_last(c, cs)) return bail();
+  const clock::time_point h_enq = clock::now();
+  if (p2p_reduce(t, n_steps, tot_u_per_step)) return bail();
+  if (t->edge_stream) P2P_RUN_TRY(hipStreamSynchronize(es));
+#undef P2P_RUN_TRY
   if (p2p_check_error(t)) return 1;
+  if (t->profile) {
+    const clock::time_point h1 = clock::now();
+    auto us = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    double* ph = t->phases;
+    std::fill(ph, ph + LBM_P2P_PHASES, 0.0);
+    ph[0] = us(h0, h1);
+    ph[1] = us(h0, h_enq);
+    ph[2] = p2p_us(e_run0, t->ev_reduce_end);
+    ph[3] = p2p_us(e_run0, e_steps0);
+    ph[4] = p2p_us(e_steps0, e_steps1);
+    ph[5] = p2p_us(e_steps1, t->ev_reduce_end);
+    ph[6] = macro_steps;
+    ph[7] = macro_steps ? ph[4] / macro_steps : 0.0;
+    if (sp_interior.size() >= 3) ph[8] = p2p_us(sp_interior[1].begin, sp_interior.back().begin) / static_cast<double>(sp_interior.size() - 2);
+    ph[9] = p2p_avg_us(sp_interior);
+    ph[10] = p2p_avg_us(sp_edge);
+    ph[11] = sp_push.empty() ? 0.0 : p2p_us(sp_push[0].begin, sp_push[0].end);
+    ph[12] = p2p_avg_us(sp_push, 1);
+    ph[13] = ph[0] - ph[2];
+    t->phases_valid = true;
+  }
   return 0;
+}
+
+int lbm_p2p_set_profile(lbm_p2p* t, int on)
+{
+  if (!t) { lbm_internal::set_error("lbm_p2p_set_profile: null argument"); return 1; }
+  t->profile = on != 0;
+  if (!t->profile) t->phases_valid = false;
+  return 0;
+}
+
+int lbm_p2p_phases(const lbm_p2p* t, double* values)
+{
+  if (!t || !values) { lbm_internal::set_error("lbm_p2p_phases: null argument"); return 1; }
+  if (!t->phases_valid) { lbm_internal::set_error("lbm_p2p_phases: no profiled run (lbm_p2p_set_profile(t, 1), then lbm_p2p_run)"); return 1; }
+  std::memcpy(values, t->phases, sizeof t->phases);
+  return 0;
+}
+
+const char* lbm_p2p_phase_name(int i)
+{
+  static const char* const names[] = {"host_total", "host_enqueue", "device_span", "setup", "steps", "reduce", "macro_steps", "macro_step_avg",
+                                      "macro_step_steady", "interior_avg", "edge_avg", "push_first", "push_avg", "host_overhead"};
+  return (i >= 0 && i < static_cast<int>(sizeof names / sizeof names[0])) ? names[i] : nullptr;
 }
 
 int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)

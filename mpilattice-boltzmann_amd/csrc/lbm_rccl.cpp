@@ -171,8 +171,8 @@ int lbm_comm_destroy(lbm_comm* c)
   return 0;
 }
 
-// K-step mode (contexts from lbm_create_global, lbm_macro_steps() = K > 0): one exchange of K whole rows
-// of each of the 9 planes per K steps, same three-queue schedule.  By default the 18 row blocks of a
+// K-step mode (contexts from lbm_create_rank / lbm_create_global, lbm_macro_steps() = K > 0): one exchange of the
+// partition's ghost rows (K whole rows of each of the 9 planes; four at K = 3) per macro-step, same three-queue schedule.  By default the 18 row blocks of a
 // direction pair are packed into one message per direction by a small kernel on the exchange stream
 // (fewer, larger messages); LBM_RCCL_PACK=0 sends them straight from the edge rows into the
 // neighbour's ghost rows as 18 + 18 messages.
@@ -188,7 +188,10 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
   LBM_TRY(lbm_macro_prepare(ctx, n_steps, c->compute));   // step-0 accelerate_flow
   HIP_TRY(hipEventRecord(c->edge_done, c->compute));
   HIP_TRY(hipEventRecord(c->interior_done, c->compute));
-  for (int done = 0; done < n_steps; done += K) {
+  (void)K;
+  for (int done = 0; done < n_steps;) {
+    const int k = lbm_macro_next_steps(ctx);                 // K, fewer at the end, or 3s and 4s (four ghost rows at K = 3)
+    if (k <= 0) { lbm_internal::set_error("lbm_comm_run: the context has no macro-step left"); return 1; }
     HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));   // the rows to send were written by the last edge launch
     if (packed) {
       // gather the 9 planes' rows into one message per direction, exchange 2 + 2 messages, scatter
@@ -219,17 +222,17 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
     HIP_TRY(hipEventRecord(c->edge_done, edge_stream));
     if (three_queues) {
       HIP_TRY(hipEventRecord(c->interior_done, c->compute));
-      if (done + K >= n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+      if (done + k >= n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
     }
     LBM_TRY(lbm_macro_finish(ctx, c->compute));
     if (c->step_allreduce) {
       // this macro-step's totals now, and the next macro-step behind their all-reduce (north_star wording)
-      const int k = std::min(K, n_steps - done);
       if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
       LBM_TRY(lbm_step_fold(ctx, c->compute));
       double* sums_now = static_cast<double*>(lbm_step_sums_device_ptr(ctx)) + done;
       NCCL_TRY(ncclAllReduce(sums_now, sums_now, static_cast<size_t>(k), ncclDouble, ncclSum, c->nccl, c->compute));
     }
+    done += k;
   }
   double* sums = static_cast<double*>(lbm_step_sums_device_ptr(ctx));
   if (c->nranks > 1 && !c->step_allreduce) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));

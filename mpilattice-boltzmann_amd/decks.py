@@ -38,10 +38,10 @@ class Params:
             fh.write(f"{self.density!r}\n{self.accel!r}\n{self.omega!r}\n")
 
 
-def splitmix64(seed: int, n: int) -> np.ndarray:
-    """First n outputs of splitmix64 seeded with `seed` (vectorised; uint64 wrap-around)."""
+def splitmix64(seed: int, n: int, first: int = 0) -> np.ndarray:
+    """Outputs first+1 .. first+n of splitmix64 seeded with `seed` (vectorised; uint64 wrap-around)."""
     with np.errstate(over="ignore"):
-        idx = np.arange(1, n + 1, dtype=np.uint64)
+        idx = np.arange(first + 1, first + n + 1, dtype=np.uint64)
         z = (np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)) & _M64
         z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
         z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
@@ -51,9 +51,15 @@ def splitmix64(seed: int, n: int) -> np.ndarray:
 def synthetic_obstacles(nx: int, ny: int, p: float = 0.005, seed: int = 42, walls: bool = True) -> np.ndarray:
     """(ny, nx) int32 map: 1 = blocked.  Cell (x, y) consumes the (y*nx+x)-th PRNG output; it is
     blocked when the top 53 bits, as a fraction of 2**53, fall below p."""
-    r = splitmix64(seed, nx * ny).reshape(ny, nx)
-    frac = (r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
-    obst = (frac < p).astype(np.int32)
+    # in cache-sized pieces: the 8192 x 8192 deck is 67 M outputs, and whole-array temporaries made this 9 s of memory traffic
+    n = nx * ny
+    flat = np.empty(n, dtype=np.int32)
+    piece = 1 << 18
+    for first in range(0, n, piece):
+        r = splitmix64(seed, min(piece, n - first), first)
+        frac = (r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        flat[first:first + r.size] = frac < p
+    obst = flat.reshape(ny, nx)
     if walls:
         obst[0, :] = 1
         obst[-1, :] = 1

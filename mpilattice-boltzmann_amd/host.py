@@ -188,6 +188,12 @@ class Partition:
         """K if the partition runs in K-step mode (lbm_macro_*), else 0."""
         return int(self._lib.lbm_macro_steps(self._ctx))
 
+    @property
+    def macro_next(self) -> int:
+        """Steps of the macro-step about to be made (`lbm_macro_next_steps`): K, fewer at the end of a run, or 3s and
+        4s where the partition keeps four ghost rows at K = 3.  0 when no run is in progress."""
+        return int(self._lib.lbm_macro_next_steps(self._ctx))
+
     def macro_prepare(self, n_steps: int, stream=None) -> None:
         check(self._lib.lbm_macro_prepare(self._ctx, n_steps, self._stream_ptr(stream)))
 
@@ -266,6 +272,18 @@ class Partition:
         ms, n = C.c_double(0.0), C.c_int(0)
         check(self._lib.lbm_last_run_kernel_ms(self._ctx, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_profile(self, on: bool) -> None:
+        """`lbm_set_profile`: timing events around every step-kernel launch of the following `run`s."""
+        check(self._lib.lbm_set_profile(self._ctx, 1 if on else 0))
+
+    def launch_profile(self) -> list[tuple[int, float]]:
+        """[(steps advanced, duration in us)] per step-kernel launch of the last profiled `run`, in order."""
+        n = C.c_int(0)
+        check(self._lib.lbm_launch_profile(self._ctx, 0, None, None, C.byref(n)))
+        steps, us = (C.c_int * max(n.value, 1))(), (C.c_double * max(n.value, 1))()
+        check(self._lib.lbm_launch_profile(self._ctx, n.value, steps, us, C.byref(n)))
+        return [(int(steps[i]), float(us[i])) for i in range(n.value)]
 
     def describe(self) -> dict:
         name = C.create_string_buffer(256)
@@ -505,10 +523,23 @@ class P2PRing:
             if bad:
                 self.close()
                 raise LbmError("peer-to-peer set-up failed on rank(s) " + "; ".join(f"{r}: {m}" for r, m in bad))
-            self.connect(box)
+            # Mapping the peers (hipIpcOpenMemHandle, hipDeviceEnablePeerAccess) can fail on ONE rank only.  The
+            # ranks therefore agree on the outcome with a second all-gather — which is also the meeting point
+            # that keeps anybody from pushing rows into a neighbour that has not mapped its peers yet — and on
+            # any failure every rank unmaps, meets again (memory another process has mapped must not be freed
+            # before that process has unmapped it) and raises the same error.
+            err = None
+            try:
+                self.connect(box)
+            except LbmError as e:
+                err = str(e)
+            outcome = [None] * size
+            dist.all_gather_object(outcome, err, group=group)
             self._connected_over_group = size > 1
-            # nobody starts pushing rows into a neighbour that has not mapped its peers yet
-            dist.barrier(group=group)
+            bad = [(r, m) for r, m in enumerate(outcome) if m is not None]
+            if bad:
+                self.close()
+                raise LbmError("peer-to-peer connect failed on rank(s) " + "; ".join(f"{r}: {m}" for r, m in bad))
         elif err is not None:
             raise LbmError(err)
 
@@ -557,6 +588,22 @@ class P2PRing:
         out = np.zeros(max(n_steps, 1), dtype=np.float64)
         check(self._lib.lbm_p2p_run(self._t, n_steps, _capi.as_double_ptr(out)))
         return out[:n_steps]
+
+    def set_profile(self, on: bool) -> None:
+        """`lbm_p2p_set_profile`: HIP timing events around the launches of the following `run`s."""
+        check(self._lib.lbm_p2p_set_profile(self._t, 1 if on else 0))
+
+    def phases(self) -> dict:
+        """Where the last profiled `run` spent its time (`lbm_p2p_phases`): {name: microseconds} (macro_steps: a count)."""
+        v = (C.c_double * _capi.P2P_PHASES)()
+        check(self._lib.lbm_p2p_phases(self._t, v))
+        out, i = {}, 0
+        while True:
+            name = self._lib.lbm_p2p_phase_name(i)
+            if not name:
+                return out
+            out[name.decode()] = float(v[i])
+            i += 1
 
     def close(self) -> None:
         """Unmap the peers, meet the other ranks (memory another process has mapped must not be freed before that

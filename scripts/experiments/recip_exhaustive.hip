@@ -1,16 +1,13 @@
 // Exhaustive check (every positive normal float): which short reciprocal sequences equal the IEEE division 1.0f / d that
 // relax_core uses (d2q9-bgk.c:574 `1.0f / local_density`; hipcc emits div_scale / rcp / 6 fma / div_fmas / div_fixup)?
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/experiments/recip_exhaustive.hip -o /tmp/recip && /tmp/recip
+// The functions under test are the SHIPPED ones: kernels/exact_math.h is the header common.h includes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include "../../mpilattice-boltzmann_amd/csrc/kernels/exact_math.h"
 
-__device__ __forceinline__ float recip_a(float d)        // rcp + one Newton step
-{
-  const float r = __builtin_amdgcn_rcpf(d);
-  const float e = __builtin_fmaf(-d, r, 1.0f);
-  return __builtin_fmaf(e, r, r);
-}
+__device__ __forceinline__ float recip_a(float d) { return recip_newton(d); }        // rcp + one Newton step (exact_math.h)
 __device__ __forceinline__ float recip_b(float d)        // rcp + Newton + one residual correction
 {
   const float r = __builtin_amdgcn_rcpf(d);
@@ -35,6 +32,24 @@ __global__ void check_guarded(unsigned long long* out /* [0] mismatches on the s
   }
   atomicAdd(&out[0], bad);
   atomicAdd(&out[1], fast);
+}
+
+// recip_exact itself, scalar and packed forms, as relax_core calls them (wave-uniform choice between the short path and
+// the division): all 2^32 bit patterns, consecutive patterns in consecutive lanes; the packed form takes pattern b in one
+// half and a pattern from the other end of the range in the other.  Bits must equal 1.0f / d, NaNs included.
+__global__ void check_shipped(unsigned long long* out /* [0] scalar mismatches, [1] packed mismatches */)
+{
+  unsigned long long bad1 = 0, bad2 = 0;
+  for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < (1ull << 32); b += (uint64_t)gridDim.x * blockDim.x) {
+    const float d = __builtin_bit_cast(float, (uint32_t)b);
+    const float e = __builtin_bit_cast(float, (uint32_t)(0xffffffffull - b) ^ 0x5a5a5a5au);
+    const uint32_t rd = __builtin_bit_cast(uint32_t, 1.0f / d), re = __builtin_bit_cast(uint32_t, 1.0f / e);
+    bad1 += __builtin_bit_cast(uint32_t, recip_exact(d)) != rd;
+    const f2 q = recip_exact(f2{d, e});
+    bad2 += (__builtin_bit_cast(uint32_t, q.x) != rd) + (__builtin_bit_cast(uint32_t, q.y) != re);
+  }
+  atomicAdd(&out[0], bad1);
+  atomicAdd(&out[1], bad2);
 }
 
 __global__ void check(unsigned long long* bad /* [2] counts + [2][8] examples */, uint32_t lo, uint32_t hi)
@@ -77,5 +92,10 @@ int main()
   unsigned long long g[2];
   hipMemcpy(g, bad, sizeof g, hipMemcpyDeviceToHost);
   std::printf("guarded by |result| >= 2^-126, all 2^32 bit patterns: %llu take the short path, %llu of them differ from 1.0f / d\n", g[1], g[0]);
-  return g[0] != 0;
+  hipMemset(bad, 0, 18 * sizeof *bad);
+  check_shipped<<<4096, 256>>>(bad);
+  unsigned long long sh[2];
+  hipMemcpy(sh, bad, sizeof sh, hipMemcpyDeviceToHost);
+  std::printf("shipped recip_exact (kernels/exact_math.h), all 2^32 bit patterns: scalar form %llu differ, packed form %llu differ from 1.0f / d\n", sh[0], sh[1]);
+  return (g[0] != 0 || sh[0] != 0 || sh[1] != 0) ? 1 : 0;
 }

@@ -48,9 +48,10 @@ def run_partitions(p, obst, size, steps, kstep):
                 for q in parts:
                     q.macro_interior(st)
                     q.macro_edge(st)
+                k = parts[0].macro_next
                 for q in parts:
                     q.macro_finish(st)
-                done += K
+                done += k
         else:
             for q in parts:
                 q.step_prepare(steps, st)

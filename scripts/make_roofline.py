@@ -3,10 +3,10 @@
 
     python scripts/make_roofline.py <tag> gpurun_out/pmc_<tag>_* [--workload 8192x8192]
 
-Every directory holds one `--pmc` pass (rocprofv3 `*counter_collection.csv`).  For the dominant step kernel
-(the instantiation with the most dispatches) the per-dispatch values of every counter are averaged, and the
-two limits the kernel can be held against are derived — both recomputable from the CSVs copied next to the
-JSON, nothing else:
+Every directory holds one `--pmc` pass (rocprofv3 `*counter_collection.csv`).  For EVERY step-kernel instantiation
+the passes dispatched (a 20-step run of the 8192 x 8192 deck is 4 x lbm_multi_kernel<3> + 2 x lbm_multi_kernel<4>) the
+per-dispatch values of every counter are averaged — `kernels[<short name>]` — and the two limits a kernel can be held
+against are derived, both recomputable from the CSVs copied next to the JSON, nothing else:
 
   HBM    bytes per launch = 2 x 1024 x FETCH_SIZE + 1024 x WRITE_SIZE   (KB counters; gfx950 reports half of a
          coalesced read stream: MI355X_MICROARCH.md §HBM; lower-bound check: every source value is read at
@@ -34,56 +34,31 @@ XCDS = 8
 
 
 def read_pass(d):
-    """{counter: (values per dispatch of the dominant kernel, durations ns)}, kernel name, source file."""
+    """{kernel name: {counter: (values per dispatch, durations ns)}}, source file — every step-kernel instantiation of the pass."""
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
-        return {}, None, None
-    rows = [r for r in csv.DictReader(open(files[0])) if re.search(r"lbm_(multi|step|tile)_kernel", r["Kernel_Name"])]
-    count = {}
-    for r in rows:
-        count[r["Kernel_Name"]] = count.get(r["Kernel_Name"], 0) + 1
-    if not count:
-        return {}, None, files[0]
-    name = max(count, key=count.get)
+        return {}, None
     out = {}
-    for r in rows:
-        if r["Kernel_Name"] != name:
+    for r in csv.DictReader(open(files[0])):
+        if not re.search(r"lbm_(multi|step|tile)_kernel", r["Kernel_Name"]):
             continue
-        vals, durs = out.setdefault(r["Counter_Name"], ([], []))
+        vals, durs = out.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], ([], []))
         vals.append(float(r["Counter_Value"]))
         durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-    return out, name, files[0]
+    return out, files[0]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("tag")
-    ap.add_argument("dirs", nargs="+")
-    ap.add_argument("--workload", default="8192x8192")
-    a = ap.parse_args()
-    nx, ny = (int(v) for v in a.workload.split("x"))
-    dst = os.path.join(ROOT, "profiles", a.tag)
-    os.makedirs(dst, exist_ok=True)
-    mean, dur_ns, kernel, sources = {}, {}, None, {}
-    for d in a.dirs:
-        counters, name, f = read_pass(d)
-        if not counters:
-            continue
-        assert kernel in (None, name), (kernel, name)
-        kernel = name
-        copy = os.path.join(dst, "pmc_" + "_".join(sorted(counters)).lower()[:80] + f"_{nx}.csv")
-        shutil.copyfile(f, copy)
-        for cname, (vals, durs) in counters.items():
-            mean[cname] = sum(vals) / len(vals)
-            dur_ns[cname] = sum(durs) / len(durs)
-            sources[cname] = {"file": os.path.relpath(copy, ROOT), "dispatches": len(vals), "min": min(vals), "max": max(vals),
-                              "mean_dispatch_ns": dur_ns[cname]}
-    m = re.search(r"lbm_multi_kernel<(\d+)", kernel or "")
-    steps = int(m.group(1)) if m else 1
-    short = f"lbm_multi_kernel<{steps}>" if m else (kernel or "").split("(")[0]
-    out = {"workload": a.workload, "kernel": short, "kernel_full_name": kernel, "steps_per_launch": steps, "round": a.tag,
-           "simds": SIMDS, "counters_mean_per_launch": mean, "source": sources,
-           "minimum_read_bytes_per_launch": 36 * nx * ny, "algorithmic_bytes_per_launch_108B": 108 * nx * ny * steps}
+def short_name(full):
+    m = re.search(r"lbm_multi_kernel<(\d+)", full)
+    if m:
+        return f"lbm_multi_kernel<{m.group(1)}>", int(m.group(1))
+    m = re.search(r"(lbm_\w+_kernel\w*)", full)
+    return (m.group(1) if m else full.split("(")[0]), 1
+
+
+def derive(mean, dur_ns, nx, ny, steps):
+    """The per-launch quantities of one kernel from its counter means (formulas of the module docstring)."""
+    out = {"steps_per_launch": steps, "minimum_read_bytes_per_launch": 36 * nx * ny, "algorithmic_bytes_per_launch_108B": 108 * nx * ny * steps}
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         rd, wr = 2.0 * 1024.0 * mean["FETCH_SIZE"], 1024.0 * mean["WRITE_SIZE"]
         out.update({"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
@@ -103,8 +78,46 @@ def main():
         out["lds_bank_conflict_frac"] = mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_ACTIVE_INST_LDS"]
     if "SQ_LDS_BANK_CONFLICT" in mean and mean.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_of_idx_active"] = mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_WAIT_ANY" in mean and mean.get("SQ_WAVE_CYCLES"):
+        out["wait_any_of_wave_cycles"] = mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("dirs", nargs="+")
+    ap.add_argument("--workload", default="8192x8192")
+    a = ap.parse_args()
+    nx, ny = (int(v) for v in a.workload.split("x"))
+    dst = os.path.join(ROOT, "profiles", a.tag)
+    os.makedirs(dst, exist_ok=True)
+    mean, dur_ns, sources, calls = {}, {}, {}, {}            # per kernel (full name)
+    for d in a.dirs:
+        per_kernel, f = read_pass(d)
+        if not per_kernel:
+            continue
+        names = sorted({c for k in per_kernel.values() for c in k})
+        copy = os.path.join(dst, "pmc_" + "_".join(names).lower()[:80] + f"_{nx}.csv")
+        shutil.copyfile(f, copy)
+        for kernel, counters in per_kernel.items():
+            for cname, (vals, durs) in counters.items():
+                mean.setdefault(kernel, {})[cname] = sum(vals) / len(vals)
+                dur_ns.setdefault(kernel, {})[cname] = sum(durs) / len(durs)
+                calls[kernel] = max(calls.get(kernel, 0), len(vals))
+                sources.setdefault(kernel, {})[cname] = {"file": os.path.relpath(copy, ROOT), "dispatches": len(vals), "min": min(vals),
+                                                         "max": max(vals), "mean_dispatch_ns": dur_ns[kernel][cname]}
+    kernels = {}
+    for kernel in mean:
+        short, steps = short_name(kernel)
+        kernels[short] = dict(derive(mean[kernel], dur_ns[kernel], nx, ny, steps), kernel_full_name=kernel, dispatches_profiled=calls[kernel],
+                              counters_mean_per_launch=mean[kernel], source=sources[kernel])
+    # the dominant kernel (advances the most steps over the profiled passes) is repeated at the top level
+    dom = max(kernels, key=lambda k: kernels[k]["steps_per_launch"] * kernels[k]["dispatches_profiled"])
+    out = {"workload": a.workload, "round": a.tag, "simds": SIMDS, "kernel": dom, "kernels": kernels}
+    out.update({k: v for k, v in kernels[dom].items() if k not in ("counters_mean_per_launch", "source")})
     json.dump(out, open(os.path.join(dst, "roofline.json"), "w"), indent=1)
-    print(json.dumps({k: v for k, v in out.items() if k not in ("source", "counters_mean_per_launch")}, indent=1))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("source", "counters_mean_per_launch")} for k, v in kernels.items()}, indent=1))
 
 
 if __name__ == "__main__":

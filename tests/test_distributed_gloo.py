@@ -59,3 +59,78 @@ def test_partitioned_run_over_gloo_equals_single_rank(lbm, oracle, size, case):
         assert np.array_equal(r["av"], ranks[0]["av"])
     assert np.allclose(ranks[0]["av"].astype(np.float64), ref_exact, rtol=1e-6)
     assert np.allclose(ranks[0]["av"], ref_av, rtol=2e-4)
+
+
+class _FakeP2PLib:
+    """Stands in for liblbm_d2q9.so's lbm_p2p_* entry points (no GPU here): create / handle succeed on every rank,
+    connect fails on the rank named in `fail_on` ONLY — what hipIpcOpenMemHandle or hipDeviceEnablePeerAccess failing
+    for one device pair looks like from the host side."""
+
+    def __init__(self, rank, fail_on):
+        self.rank, self.fail_on, self.calls = rank, fail_on, []
+
+    def lbm_p2p_create(self, out, *a):
+        out._obj.value = 1                                # a non-null lbm_p2p*: close() has something to free
+        return 0
+
+    def lbm_p2p_handle(self, t, buf):
+        return 0
+
+    def lbm_p2p_connect(self, t, blobs):
+        self.calls.append("connect")
+        return 1 if self.rank == self.fail_on else 0
+
+    def lbm_p2p_disconnect(self, t):
+        self.calls.append("disconnect")
+        return 0
+
+    def lbm_p2p_destroy(self, t):
+        self.calls.append("destroy")
+        return 0
+
+    def lbm_last_error(self):
+        return b"hipIpcOpenMemHandle: invalid device pointer"
+
+
+def _connect_worker(rank, size, init_file, fail_on, out_dir):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch.distributed as dist
+    import mpilattice_boltzmann_amd as lbm
+    from mpilattice_boltzmann_amd import _capi, host
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=size)
+    fake = _FakeP2PLib(rank, fail_on)
+    _capi.load_library = lambda: fake                     # host.P2PRing and check() resolve the library through _capi
+
+    class Part:                                           # only ._ctx is touched before connect
+        _ctx = C.c_void_p(1)
+    what = "connected"
+    try:
+        ring = lbm.P2PRing(Part(), None)
+        ring._t = C.c_void_p(0)                           # nothing for __del__ to do
+    except lbm.LbmError as e:
+        what = str(e)
+    # the ranks must still be in step with one another: a collective right after the constructor pairs up
+    flag = [None] * size
+    dist.all_gather_object(flag, rank)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+        fh.write(what + "\n" + ",".join(fake.calls) + "\n" + ",".join(str(v) for v in flag))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("size,fail_on", [(2, 1), (3, 0), (3, -1)])
+def test_p2p_connect_failure_on_one_rank_is_raised_on_every_rank(lbm, size, fail_on):
+    """lbm_p2p_connect failing on ONE rank used to raise there alone while the others sat in a barrier —
+    mismatched collectives from then on.  Now the outcome is agreed on: every rank raises the same LbmError, unmaps
+    and frees, and the process group is still in step afterwards."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_connect_worker, args=(size, os.path.join(tmp, "rendezvous"), fail_on, tmp), nprocs=size, join=True)
+        got = [open(os.path.join(tmp, f"rank{r}.txt")).read().split("\n") for r in range(size)]
+    for r, (what, calls, flag) in enumerate(got):
+        assert flag == ",".join(str(v) for v in range(size))
+        if fail_on < 0:
+            assert what == "connected" and calls == "connect"
+        else:
+            assert what.startswith(f"peer-to-peer connect failed on rank(s) {fail_on}: ") and "hipIpcOpenMemHandle" in what
+            assert calls == "connect,disconnect,destroy"

@@ -159,7 +159,7 @@ def test_set_cells_random_state(lbm, oracle, kernel_form):
 
 def test_short_reciprocal_equals_the_division_on_every_float(tmp_path):
     """relax_core's 1.0f / density (d2q9-bgk.c:561) is v_rcp_f32 + one Newton step wherever the result is a normal number and
-    the compiler's IEEE division elsewhere (kernels/common.h recip_exact).  That the two agree is not an argument but a
+    the compiler's IEEE division elsewhere (kernels/exact_math.h recip_exact, included by the enumeration program).  That the two agree is not an argument but a
     count: all 2^32 bit patterns, on this GPU, every run of the suite (about a second)."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -169,10 +169,12 @@ def test_short_reciprocal_equals_the_division_on_every_float(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 of them differ" in r.stdout, r.stdout
+    # ... and the shipped functions themselves (kernels/exact_math.h, the header common.h includes), scalar and packed
+    assert "shipped recip_exact (kernels/exact_math.h), all 2^32 bit patterns: scalar form 0 differ, packed form 0 differ" in r.stdout, r.stdout
 
 
 def test_short_double_sqrt_is_correctly_rounded_on_every_float(tmp_path):
-    """sqrt((double)u_sq) of d2q9-bgk.c:667 is v_rsq_f64 + two Newton corrections (kernels/common.h sqrt_of_float), four
+    """sqrt((double)u_sq) of d2q9-bgk.c:667 is v_rsq_f64 + two Newton corrections (kernels/exact_math.h sqrt_of_float, included by the enumeration program), four
     instructions fewer than the compiler's sequence.  Enumerated against the correctly rounded square root on all
     2 139 095 041 non-negative floats, every run of the suite."""
     import shutil
@@ -182,8 +184,8 @@ def test_short_double_sqrt_is_correctly_rounded_on_every_float(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", src, "-o", exe], check=True, capture_output=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    line = [l for l in r.stdout.splitlines() if "sqrt_of_float" in l]
-    assert line and line[0].split()[-1] == "0", r.stdout
+    line = [l for l in r.stdout.splitlines() if "SHIPPED kernels/exact_math.h sqrt_of_float" in l or "<- the shipped form" in l]
+    assert len(line) == 2 and all(l.split()[-1] == "0" for l in line), r.stdout
 
 
 @pytest.mark.parametrize("form", ["vector", "tile", "multi"])
@@ -626,9 +628,11 @@ def _k_step_partitions_in_process(lbm, parts, steps, K):
             for part in parts:
                 part.macro_interior(st)
                 part.macro_edge(st)
+            k = parts[0].macro_next                                              # K, or 3s and 4s; the same on every partition
+            assert 1 <= k <= 4 and all(part.macro_next == k for part in parts)
             for part in parts:
                 part.macro_finish(st)
-            done += K
+            done += k
         sums = sum(part.step_collect(steps, st) for part in parts)
     tstream.synchronize()
     return sums
@@ -797,9 +801,11 @@ def test_k_step_partitions_with_rows_the_tile_does_not_divide(lbm, oracle, monke
             for part in parts:
                 part.macro_interior(st)
                 part.macro_edge(st)
+            k = parts[0].macro_next                                              # K, or 3s and 4s; the same on every partition
+            assert 1 <= k <= 4 and all(part.macro_next == k for part in parts)
             for part in parts:
                 part.macro_finish(st)
-            done += K
+            done += k
         sums = sum(part.step_collect(steps, st) for part in parts)
     tstream.synchronize()
     cells = np.concatenate([part.get_cells() for part in parts], axis=0)
@@ -998,6 +1004,67 @@ def test_p2p_ranks_in_separate_processes_share_the_gpu(lbm, ranks):
     assert r.returncode == 0 and len(lines) == len(P2P_CASES[ranks]) and all(" ok " in l for l in lines), (r.stdout[-2000:], r.stderr[-3000:])
 
 
+# Cases for a box with SEVERAL GPUs (one rank per device, over real links): both native loops, north_star's per-step
+# all-reduce, ny % size != 0, step counts K does not divide (3s and 4s at K = 3), one-step mode, repeated runs, the scatter.
+MULTI_GPU_CASES = {
+    2: [dict(nx=2048, ny=2050, K=0, schedule="", runs=[20, 11], walls=True, p=0.005), dict(nx=192, ny=99, K=3, schedule="serial", runs=[7, 24]),
+        dict(nx=130, ny=100, K=4, schedule="edge", runs=[31], scatter=True),
+        dict(nx=2048, ny=2050, K=0, schedule="", runs=[20, 11], walls=True, p=0.005, exchange="rccl"),
+        dict(nx=192, ny=99, K=3, schedule="serial", runs=[7, 24], exchange="rccl"),
+        dict(nx=512, ny=70, K=2, schedule="edge", runs=[31], scatter=True, exchange="rccl", step_allreduce=True),
+        dict(nx=1024, ny=1024, K=0, schedule="", runs=[13, 2], walls=True, exchange="rccl", step_allreduce=True),
+        dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6], exchange="rccl")],
+    3: [dict(nx=256, ny=200, K=3, schedule="edge", runs=[20, 11]), dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
+        dict(nx=256, ny=200, K=3, schedule="", runs=[20, 11], exchange="rccl", scatter=True),
+        dict(nx=1000, ny=400, K=0, schedule="", runs=[16], walls=True, exchange="rccl", step_allreduce=True),
+        dict(nx=37, ny=45, K=0, schedule="", runs=[19], scatter=True), dict(nx=37, ny=45, K=0, schedule="", runs=[19], exchange="rccl", step_allreduce=True)],
+}
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_native_loops_with_one_gpu_per_rank(lbm, ranks):
+    """Switches itself on when the box has at least `ranks` GPUs: the peer-to-peer loop and the RCCL loop (with and
+    without one all-reduce per macro-step) as fresh rank processes, ONE DEVICE EACH — stores, flags and RCCL messages
+    over real links, ncclCommInitRank / ncclSend / ncclRecv / ncclAllReduce with nranks > 1 — against the oracle bit
+    for bit (tests/p2p_worker.py).  On the one-GPU box the same worker runs with all ranks on device 0
+    (test_p2p_ranks_in_separate_processes_share_the_gpu); RCCL refuses that, hence this test."""
+    import json
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < ranks:
+        pytest.skip(f"needs {ranks} GPUs, this box has {torch.cuda.device_count()}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBM_P2P_TIMEOUT_MS="20000", LBM_WORKER_DEVICE="local_rank", GLOO_SOCKET_IFNAME="lo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), json.dumps(MULTI_GPU_CASES[ranks])]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
+    assert r.returncode == 0 and len(lines) == len(MULTI_GPU_CASES[ranks]) and all(" ok " in l for l in lines), (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_bench_on_two_gpus_harvests_every_part(lbm):
+    """Switches itself on with >= 2 GPUs: the driver's own N = 2 invocation on a smaller deck — headline over p2p, phases,
+    both RCCL variants and the shipped 1024x1024 deck on two real devices, every part parity-checked."""
+    import json
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "4096x4096",
+                        "--secondary-steps", "2000"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["config"]["loop"] == "p2p" and out["parity_check"]["ok"] is True and "truncated" not in out
+    assert out["variants"]["rccl"]["parity_ok"] is True and out["variants"]["rccl"]["rccl_nranks"] == 2
+    assert out["variants"]["rccl_step_allreduce"]["parity_ok"] is True and out["variants"]["rccl_step_allreduce"]["step_allreduce"] is True
+    sec = out["secondary"]["input_1024x1024"]
+    assert sec["p2p"]["parity_ok"] is True and sec["rccl"]["parity_ok"] is True
+    assert out["phases"]["max_over_ranks"]["macro_steps"] == 6 and len(out["phases"]["per_rank"]) == 2
+
+
 @pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge")])
 def test_p2p_partitions_in_one_process(lbm, nx, ny, size, K, schedule):
     """Several ranks of one run as contexts of ONE process (one host thread per rank, as a single-process
@@ -1056,15 +1123,26 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(LBM_FORCE_DEVICE="0", LBM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--reps", "3",
-                        "--workload", "2048x2048"], capture_output=True, text=True, timeout=900, env=env)
+                        "--workload", "2048x2048", "--secondary-steps", "3000"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0 and "truncated" not in out
     assert out["config"]["loop"] == "p2p" and out["config"]["macro_k"] == 3 and "ipc" in out["config"]["p2p"]
     assert out["parity_check"]["ok"] is True and out["exchange_attempts"][0] == {"exchange": "p2p", "ok": True}
     assert out["launch_attempts"][0]["returncode"] == 0
+    # what one multi-rank invocation harvests beside the headline: phases of a profiled repetition,
+    # the RCCL variants (here: recorded as not usable, the two ranks share this box's one GPU — not a crash), and
+    # BASELINE.json config 4, the shipped 1024 x 1024 deck on the same ranks
+    ph = out["phases"]
+    assert len(ph["per_rank"]) == 2 and ph["max_over_ranks"]["macro_steps"] == 6            # 20 = 4 + 4 + 3 + 3 + 3 + 3
+    for name in ("host_total", "setup", "steps", "reduce", "macro_step_avg", "interior_avg", "push_first", "push_avg", "host_overhead"):
+        assert ph["max_over_ranks"][name] > 0, name
+    for name in ("rccl", "rccl_step_allreduce"):
+        assert "ranks share a GPU" in out["variants"][name]["error"]
+    sec = out["secondary"]["input_1024x1024"]
+    assert sec["steps"] == 3000 and sec["p2p"]["parity_ok"] is True and sec["p2p"]["value"] > 0 and "ranks share a GPU" in sec["rccl"]["error"]
 
 
 @pytest.mark.parametrize("gpus,name", [(2, "256x256_t1000"), (3, "1024x1024_t200"), (4, "128x256_t2000"), (4, "rand_64x48"), (3, "tall_8x256")])

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lbm):
     assert declared <= exported, declared - exported
     assert declared == set(lbm.EXPORTS), declared ^ set(lbm.EXPORTS)
     lib = lbm.load_library()
-    assert lib.lbm_abi_version() == 2
+    assert lib.lbm_abi_version() == 3 == lbm._capi.ABI_VERSION
 
 
 def test_p2p_entry_points_are_exported_by_the_core_library(lbm):
@@ -30,7 +30,7 @@ def test_p2p_entry_points_are_exported_by_the_core_library(lbm):
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(lbm_p2p_[a-z_0-9]+)\s*\(", header))
     assert declared == {"lbm_p2p_create", "lbm_p2p_handle", "lbm_p2p_connect", "lbm_p2p_disconnect", "lbm_p2p_destroy", "lbm_p2p_run",
-                        "lbm_p2p_describe"}
+                        "lbm_p2p_describe", "lbm_p2p_set_profile", "lbm_p2p_phases", "lbm_p2p_phase_name"}
     nm = subprocess.run(["nm", "-D", "--defined-only", lbm.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert declared <= set(re.findall(r" T (lbm_[a-z_0-9]+)", nm))
     assert declared == set(lbm.P2P_EXPORTS)
@@ -166,7 +166,7 @@ def test_rank_layout_is_one_decision_for_all_ranks(lbm):
         nyl, dis = lbm.decompose(ny, size)
         assert [l["ny_local"] for l in lays] == nyl and [l["y0"] for l in lays] == dis
         assert len({l["macro_k"] for l in lays}) == 1, lays
-        assert all(l["ghost"] == l["macro_k"] for l in lays)
+        assert all(l["ghost"] == (4 if l["macro_k"] == 3 else l["macro_k"]) for l in lays)   # four ghost rows at K = 3: runs end in 3s and 4s
         k = lays[0]["macro_k"]
         if size == 1:
             assert k == 0                                            # a whole periodic grid needs no ghost rows ...
@@ -368,3 +368,78 @@ def test_roofline_json_recomputes_from_the_committed_counter_files():
     frac_hbm = hbm / (0.5 * (dur["FETCH_SIZE"] + dur["WRITE_SIZE"])) / 8.0e12
     assert abs(frac_hbm / roof["frac_hbm_physical_profiled"] - 1.0) < 1e-9
     assert 0.0 < frac_valu < 1.0 and 0.0 < frac_hbm < 1.0                      # fractions of something the chip delivers
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_fallback_chain_and_budget_fit_the_drivers_limit():
+    """the driver kills a bench run at 600 s.  Self-launched, the three-mode worst case (every set of rank
+    processes hanging until --launch-timeout) must sum below 500 s, the ranks' own budget must end before their launcher
+    gives up on them, and a rank started directly by the driver (no launcher) prints what it has at 420 s."""
+    bench = _bench_module()
+    a = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    modes = bench.launch_modes(a)
+    assert modes == ["auto", "rccl", "torch"]
+    assert len(modes) * a.launch_timeout < 500.0
+    assert a.budget_s == 0.0                                        # default: 420 s in a rank, launch_timeout - 25 under the launcher
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "budget = args.budget_s if args.budget_s > 0 else 420.0" in src and 'os.environ.setdefault("LBM_P2P_TIMEOUT_MS", "10000")' in src
+    assert bench.parse_args(["--exchange", "p2p"]).exchange == "p2p" and bench.launch_modes(bench.parse_args(["--exchange", "p2p"])) == ["p2p"]
+
+
+def test_bench_watchdog_prints_the_banked_line_when_the_budget_runs_out(tmp_path):
+    """A rank that hangs after its headline (a collective that never returns, a kernel that never ends) must not take the
+    line with it: at the end of the budget rank 0 prints what was banked, marked `truncated`, and leaves with exit code 0;
+    with nothing banked it prints an error line and leaves with 1.  Exactly one line either way."""
+    import json
+    import sys
+    prog = ("import sys, time, importlib.util\n"
+            f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r}); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "b.quiet_stdout()\n"
+            "b.start_watchdog(0, 2, 1.0, time.time())\n"
+            "if sys.argv[1] == 'banked':\n"
+            "    b.bank({'metric': 'MLUPS', 'value': 1.0})\n"
+            "b.stage('variant: rccl')\n"
+            "print('noise on stdout')\n"
+            "time.sleep(30)\n")
+    for what, code in (("banked", 0), ("nothing", 1)):
+        r = subprocess.run([sys.executable, "-c", prog, what], capture_output=True, text=True, timeout=60)
+        assert r.returncode == code, r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        if what == "banked":
+            assert out["value"] == 1.0 and out["truncated"] == "budget of 1 s ran out during: variant: rccl"
+        else:
+            assert "ran out during: variant: rccl" in out["error"] and "value" not in out
+
+
+def test_bench_roofline_object_weights_the_launch_mix():
+    """ADVICE r02 / VERDICT r02 item 4: a 20-step run is 4 x K=3 + 2 x K=4 launches (or 2 x K=4 + 4 x K=3): every
+    instantiation's bytes are divided by ITS OWN live duration, `frac` is the dominant kernel's physical HBM fraction,
+    the §8(d) figure (108 B x cells x steps / time) is stated beside it, and the VALU share is labelled a constant."""
+    bench = _bench_module()
+    cells = 8192 * 8192
+    pmc = {"workload": "8192x8192", "kernels": {
+        "lbm_multi_kernel<3>": {"steps_per_launch": 3, "hbm_bytes_per_launch": 5.4e9, "frac_valu_profiled": 0.8, "lds_bank_conflict_frac": 0.9},
+        "lbm_multi_kernel<4>": {"steps_per_launch": 4, "hbm_bytes_per_launch": 5.9e9, "frac_valu_profiled": 0.85}}}
+    prof = [(4, 1500.0), (4, 1480.0), (3, 1010.0), (3, 1000.0), (3, 990.0), (3, 1000.0)]
+    r = bench.roofline_object("lbm_multi_kernel<3>", 8192, 8192, float(cells), prof, 1.2e-3, 6, 20, pmc)
+    assert r["kernel"] == "lbm_multi_kernel<3>" and r["steps_per_launch"] == 3 and r["bound"] == "hbm" and r["peak"] == 8000.0
+    assert abs(r["avg_launch_ms"] - 1.0) < 1e-9 and abs(r["achieved"] - 5400.0) < 1e-6 and abs(r["frac"] - 0.675) < 1e-9 and r["traffic"] == 5.4e9
+    assert abs(r["by_section_8d"]["frac"] - 108.0 * cells * 3 / 1.0e-3 / 8.0e12) < 1e-9 and r["by_section_8d"]["frac"] > 2.0
+    k4 = r["run_mix"]["K4"]
+    assert k4["launches"] == 2 and abs(k4["frac_hbm_physical"] - 5.9e9 / 1.49e-3 / 8.0e12) < 1e-9
+    total = (4 * 5.4e9 + 2 * 5.9e9) / (4 * 1.0e-3 + 2 * 1.49e-3) / 8.0e12
+    assert abs(r["frac_hbm_physical_run"] - total) < 1e-9
+    assert r["limits"]["valu"] == {"frac": 0.8, "kind": "profiled-pass constant", "note": r["limits"]["valu"]["note"]}
+    # a partitioned run has no per-launch timing: the whole-run average, bytes scaled by cells and steps per launch
+    r2 = bench.roofline_object("lbm_multi_kernel<3>", 8192, 8192, cells / 8.0, None, 150e-6, 7, 20, pmc, scale=1.0 / 8.0)
+    assert r2["scaled_from_single_gpu_pmc"] is True and abs(r2["traffic"] - 5.4e9 / 8.0 * (20.0 / 7.0) / 3.0) < 1.0
+    assert abs(r2["by_section_8d"]["frac"] - 108.0 * cells / 8.0 * (20.0 / 7.0) / 150e-6 / 8.0e12) < 1e-9
