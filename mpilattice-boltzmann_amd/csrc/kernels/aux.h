@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(kBlock) lbm_fold_slices_kernel(const double* p
   if (threadIdx.x == 0) slice_sums[v * kFoldSlices + b] = s;
 }
 
-__global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, int nvecs, double* sums, int* counter)
+// reset: this is the last fold of a run — leave the counter at 0 for the next run (saves that run a memset launch).
+__global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials, int n, int nvecs, double* sums, int* counter, int reset)
 {
   __shared__ double red[kBlock / 64];
   for (int v = 0; v < nvecs; ++v) {
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials
     if (threadIdx.x == 0) sums[*counter + v] = s;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *counter += nvecs;
+  if (threadIdx.x == 0) *counter = reset ? 0 : *counter + nvecs;
 }
 
 // accelerate_flow (d2q9-bgk.c:442-478) in place on one row: only needed before the first step of a run.

@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -124,6 +125,7 @@ struct lbm_ctx {
   int sums_cap = 0;
   double* sums_host = nullptr;   // pinned, sums_cap doubles
   int* counter = nullptr;
+  bool counter_clean = false;   // the device counter is 0 (left so by the last fold of the previous run): begin_run needs no memset
   hipStream_t stream = nullptr;
   // launch-bound grids: kGraphSteps steps captured once into a hipGraph and replayed (one per
   // starting source grid); see lbm_run
@@ -323,7 +325,10 @@ hipEvent_t prof_stamp(lbm_ctx* c, hipStream_t s)
 int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
 {
   if (ensure_sums(c, n_steps)) return 1;
-  HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(int), s));
+  // the per-step sums of a run go to sums[counter++]: the counter starts at 0.  The last fold of a run leaves it there
+  // (fold_last(final)); a memset launch — a kernel boundary on the critical path of a short run — only when it did not
+  if (!c->counter_clean) HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(int), s));
+  c->counter_clean = false;
   c->run_steps = n_steps;
   c->run_done = 0;
   c->n_prev = 0;
@@ -343,21 +348,41 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
   return 0;
 }
 
-// d2q9-bgk.c:367 for the LAST launch of a run: its per-block sums have no following launch to fold them.
-int fold_last(lbm_ctx* c, hipStream_t s)
+// d2q9-bgk.c:367 for the LAST launch of a (macro-)step sequence: its per-block sums have no following launch to fold them.
+// final: the run ends here — the fold also resets the counter for the next run.
+int fold_last(lbm_ctx* c, hipStream_t s, bool final = false)
 {
   if (c->n_prev == 0) return 0;          // already folded (lbm_step_fold)
   const double* part = c->partials[c->parity ^ 1];
   if (c->n_prev >= 8192) {
     hipLaunchKernelGGL(lbm_fold_slices_kernel, dim3(kFoldSlices, c->n_prev_vecs), dim3(kBlock), 0, s, part, c->n_prev, c->fold_scratch);
-    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->fold_scratch, kFoldSlices, c->n_prev_vecs, c->sums, c->counter);
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->fold_scratch, kFoldSlices, c->n_prev_vecs, c->sums, c->counter, final ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, part, c->n_prev, c->n_prev_vecs, c->sums, c->counter);
+    hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, part, c->n_prev, c->n_prev_vecs, c->sums, c->counter, final ? 1 : 0);
   }
   HIP_TRY(hipGetLastError());
   c->n_prev = 0;
   c->n_prev_vecs = 1;
+  c->counter_clean = final;
   return 0;
+}
+
+// Wait for the stream's work like hipStreamSynchronize, but by polling for the first milliseconds: a blocked host thread
+// is woken ~15 us after the last kernel ends, which a 1 ms run of 20 steps on 8 GPUs notices (1.5 %).  Runs that last
+// longer fall through to the blocking wait, so a long run does not keep a core spinning.  LBM_SPIN_WAIT_US: 0 = never poll.
+hipError_t stream_wait(hipStream_t s)
+{
+  const int spin_us = tune_env("LBM_SPIN_WAIT_US", 4000);       // read per call: scripts/ab_ring.py alternates it in one process
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) return e;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
+    (void)hipGetLastError();             // hipErrorNotReady is not an error
+  }
+  return hipStreamSynchronize(s);
 }
 
 // Steps of the next launch of lbm_multi_kernel when `left` steps remain: multi_K, except that at K = 3 a count that 3
@@ -817,16 +842,16 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
   HIP_TRY(hipEventRecord(c->ev_end, s));
   c->ev_launches = (multi || c->tile_kernel) ? c->ev_tile_launches : n_steps;
   c->ev_valid = true;
-  if (fold_last(c, s)) return 1;
+  if (fold_last(c, s, /*final=*/true)) return 1;
   c->run_done = n_steps;
   if (av_vels) {
     const double* host = c->sums_host;
     HIP_TRY(hipMemcpyAsync(c->sums_host, c->sums, sizeof(double) * n_steps, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
     const double inv = static_cast<double>(c->free_cells_inv);
     for (int t = 0; t < n_steps; ++t) av_vels[t] = static_cast<float>(host[t] * inv);   // d2q9-bgk.c:367
   } else {
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_wait(s));
   }
   return 0;
 }
@@ -1026,7 +1051,7 @@ int lbm_step_finish(lbm_ctx* c, void* stream)
     HIP_TRY(hipEventRecord(c->ev_end, s));
     c->ev_launches = c->run_steps * ((c->n_part_interior > 0 ? 1 : 0) + 1);
     c->ev_valid = true;
-    if (fold_last(c, s)) return 1;
+    if (fold_last(c, s, /*final=*/true)) return 1;
   }
   return 0;
 }
@@ -1156,7 +1181,7 @@ int lbm_macro_finish(lbm_ctx* c, void* stream)
     HIP_TRY(hipEventRecord(c->ev_end, s));
     c->ev_launches = c->ev_tile_launches;
     c->ev_valid = true;
-    if (fold_last(c, s)) return 1;
+    if (fold_last(c, s, /*final=*/true)) return 1;
   }
   return 0;
 }
@@ -1186,7 +1211,7 @@ int lbm_step_collect(lbm_ctx* c, void* stream, double* tot_u_per_step, int n_ste
   if (!c || !tot_u_per_step || n_steps > c->run_done) { lbm_internal::set_error("lbm_step_collect: bad argument"); return 1; }
   hipStream_t s = pick_stream(c, stream);
   HIP_TRY(hipMemcpyAsync(tot_u_per_step, c->sums, sizeof(double) * n_steps, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(stream_wait(s));
   return 0;
 }
 

@@ -201,7 +201,7 @@ int p2p_reduce(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     hipLaunchKernelGGL(lbm_p2p_allreduce_kernel, dim3(t->nranks), dim3(256), 0, cs, a);
     HIP_TRY(hipGetLastError());
     t->ev_reduce_end = p2p_stamp(t, cs);
-    HIP_TRY(hipStreamSynchronize(cs));
+    HIP_TRY(stream_wait(cs));
     std::memcpy(tot_u_per_step + t0, t->reduce_out, sizeof(double) * n);     // host-mapped: the kernel wrote it in place
   }
   return 0;
@@ -628,7 +628,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
   hipEvent_t e_steps1 = p2p_stamp(t, cs);
   c->ev_launches = c->ev_tile_launches;
   c->ev_valid = true;
-  if (fold_last(c, cs)) return bail();
+  if (fold_last(c, cs, /*final=*/true)) return bail();
   const clock::time_point h_enq = clock::now();
   if (p2p_reduce(t, n_steps, tot_u_per_step)) return bail();
   if (t->edge_stream) P2P_RUN_TRY(hipStreamSynchronize(es));

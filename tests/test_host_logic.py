@@ -325,7 +325,7 @@ def test_bench_starts_its_own_rank_processes(n):
     assert out["launch_attempts"][0]["returncode"] == 0
 
 
-@pytest.mark.parametrize("name", ["recip_exhaustive.hip", "sqrt_exhaustive.hip", "grid_barrier.hip"])
+@pytest.mark.parametrize("name", ["recip_exhaustive.hip", "sqrt_exhaustive.hip", "grid_barrier.hip", "xcd_handoff.hip"])
 def test_enumeration_programs_compile_for_gfx950(tmp_path, name):
     """The exhaustive checks behind the short reciprocal and the short double sqrt run on the GPU box (test_gpu_parity.py
     compiles them there); here only that they cross-compile, so a typo cannot turn those GPU tests red."""
@@ -443,3 +443,65 @@ def test_bench_roofline_object_weights_the_launch_mix():
     r2 = bench.roofline_object("lbm_multi_kernel<3>", 8192, 8192, cells / 8.0, None, 150e-6, 7, 20, pmc, scale=1.0 / 8.0)
     assert r2["scaled_from_single_gpu_pmc"] is True and abs(r2["traffic"] - 5.4e9 / 8.0 * (20.0 / 7.0) / 3.0) < 1.0
     assert abs(r2["by_section_8d"]["frac"] - 108.0 * cells / 8.0 * (20.0 / 7.0) / 150e-6 / 8.0e12) < 1e-9
+
+
+def _pmc_means(directory):
+    """{kernel full name: ({counter: mean per dispatch}, {counter: mean dispatch seconds})} from the committed rocprofv3 --pmc CSVs."""
+    import csv
+    import glob
+    acc = {}
+    for f in glob.glob(os.path.join(directory, "pmc_*.csv")):
+        for r in csv.DictReader(open(f)):
+            if "lbm_multi_kernel" not in r["Kernel_Name"]:
+                continue
+            v, t = acc.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], ([], []))
+            v.append(float(r["Counter_Value"]))
+            t.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return {k: ({c: sum(v) / len(v) for c, (v, t) in d.items()}, {c: sum(t) / len(t) * 1e-9 for c, (v, t) in d.items()}) for k, d in acc.items()}
+
+
+def test_saved_driver_style_line_recomputes_from_the_committed_counter_files():
+    """every roofline.* fraction of a saved driver-style bench line (profiles/r03/bench_n1_driver_style.json:
+    --steps 20 --warmup 5, i.e. 2 x lbm_multi_kernel<4> + 4 x lbm_multi_kernel<3> launches) follows, within 2 %, from the
+    rocprofv3 --pmc CSVs committed beside it and the launch durations the line itself states — bytes of each instantiation
+    over ITS OWN duration, the run's fraction weighted by the launches it made, the §8(d) figure, the VALU share."""
+    import csv
+    import json
+    d = os.path.join(ROOT, "profiles", "r03")
+    line = json.load(open(os.path.join(d, "bench_n1_driver_style.json")))
+    roof = line["roofline"]
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["config"]["nx"] == 8192 == line["config"]["ny"]
+    pmc = _pmc_means(d)
+    cells = 8192 * 8192
+    full = {k: [n for n in pmc if f"lbm_multi_kernel<{k}, false, 64>" in n][0] for k in (3, 4)}
+    mix = roof["run_mix"]
+    assert {k: m["launches"] for k, m in mix.items()} == {"K3": 4, "K4": 2}
+    bytes_run = time_run = 0.0
+    for k in (3, 4):
+        mean, dur = pmc[full[k]]
+        hbm = 2.0 * 1024.0 * mean["FETCH_SIZE"] + 1024.0 * mean["WRITE_SIZE"]          # gfx950: FETCH_SIZE reports half of a coalesced read stream
+        assert hbm >= 2 * 36 * cells * 0.99                                             # every value read once and written once at least
+        m = mix[f"K{k}"]
+        t = m["avg_launch_ms"] * 1e-3
+        assert abs(m["hbm_bytes_per_launch"] / hbm - 1.0) < 0.02
+        assert abs(m["frac_hbm_physical"] / (hbm / t / 8.0e12) - 1.0) < 0.02
+        assert abs(m["by_section_8d_frac"] / (108.0 * cells * k / t / 8.0e12) - 1.0) < 0.02
+        bytes_run += hbm * m["launches"]
+        time_run += t * m["launches"]
+    assert roof["kernel"] == "lbm_multi_kernel<3>" and roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] / mix["K3"]["frac_hbm_physical"] - 1.0) < 1e-9 and abs(roof["achieved"] / roof["peak"] / roof["frac"] - 1.0) < 1e-9
+    assert abs(roof["traffic"] / mix["K3"]["hbm_bytes_per_launch"] - 1.0) < 1e-9
+    assert abs(roof["frac_hbm_physical_run"] / (bytes_run / time_run / 8.0e12) - 1.0) < 0.02
+    assert abs(roof["by_section_8d"]["frac"] / mix["K3"]["by_section_8d_frac"] - 1.0) < 1e-9 and roof["by_section_8d"]["frac"] > 1.0
+    mean, dur = pmc[full[3]]
+    clock = mean["GRBM_GUI_ACTIVE"] / 8 / dur["GRBM_GUI_ACTIVE"]
+    frac_valu = 4.0 * mean["SQ_ACTIVE_INST_VALU"] / (dur["SQ_ACTIVE_INST_VALU"] * clock * 1024)
+    assert abs(roof["limits"]["valu"]["frac"] / frac_valu - 1.0) < 0.02 and roof["limits"]["valu"]["kind"] == "profiled-pass constant"
+    assert 0.0 < roof["frac"] < 1.0 and 0.0 < frac_valu < 1.0                           # fractions of something the chip delivers
+    # the rocprofv3 --kernel-trace --stats summary of the same command (200-step bench) agrees with live launch durations:
+    # the 200-step line of the same session against the trace's average for the dominant kernel
+    stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(d, "kernel_stats_bench_8192.csv")))}
+    long_line = json.load(open(os.path.join(d, "bench_n1.json")))
+    avg_ns = float(stats[full[3]]["AverageNs"])
+    assert abs(long_line["roofline"]["avg_launch_ms"] * 1e6 / avg_ns - 1.0) < 0.10
+    assert int(stats[full[3]]["Calls"]) >= 30
