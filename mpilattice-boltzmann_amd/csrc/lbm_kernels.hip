@@ -52,6 +52,7 @@
 #include "kernels/step.h"
 #include "kernels/tile.h"
 #include "kernels/multi.h"
+#include "kernels/sweep.h"
 #include "kernels/aux.h"
 #include "kernels/p2p.h"
 
@@ -144,6 +145,9 @@ struct lbm_ctx {
   int multi_tiles_x = 0, multi_tiles = 0;
   int multi_tx = kMTX;       // tile width of lbm_multi_kernel: 64, or 32 for partitions of one round of blocks
   bool multi_tail4 = true;   // lbm_run at K = 3: 4-step launches instead of a 1- or 2-step tail (LBM_TUNE_MULTI_TAIL4)
+  int sweep_R = 0;           // > 0: lbm_run's 3-step launches are lbm_sweep_kernel<R> (streaming temporal blocking, kernels/sweep.h)
+  int sweep_nseg = 0, sweep_seg_rows = 0;
+  int sweep_mode = 2;        // storage form of the pipeline (kernels/sweep.h SweepGeom; LBM_TUNE_SWEEP_MODE)
   bool tile_kernel = false;  // lbm_run advances several steps per launch with lbm_tile_kernel (small grids)
   int tile_T = 16, tile_H = 8;   // its geometry: owned tile edge, ghost ring = max steps per launch
   int tile_single_max = 0;       // sub-steps with regions of at most this many cells deal one cell per lane
@@ -293,6 +297,43 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
     case 3: launch_multi_k<3>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
     default: launch_multi_k<4>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
   }
+}
+
+// One launch of lbm_sweep_kernel: three steps of a whole periodic grid, strips of 64 columns swept upwards.
+template <int R, int MODE>
+void launch_sweep_r(lbm_ctx* c, bool accel_last, hipStream_t s)
+{
+  SweepArgs a{};
+  const float* src = c->grid[c->cur];
+  float* dst = c->grid[c->cur ^ 1];
+  for (int k = 0; k < 9; ++k) { a.srck[k] = src + k * c->ps; a.dstk[k] = dst + k * c->ps; }
+  a.ps = static_cast<uint32_t>(c->ps);
+  a.mask = c->mask; a.nx = c->p.nx; a.ny = c->nyl;
+  a.strips_x = c->p.nx / kSTX; a.nseg = c->sweep_nseg; a.seg_rows = c->sweep_seg_rows;
+  a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
+  a.accel_row = c->p.ny - 2; a.accel_last = accel_last ? 1 : 0;
+  a.partials_out = c->partials[c->parity];
+  a.prev_partials = c->partials[c->parity ^ 1];
+  a.n_prev = c->n_prev; a.n_prev_vecs = c->n_prev > 0 ? c->n_prev_vecs : 0;
+  a.sums = c->sums; a.counter = c->counter;
+  const int blocks = a.strips_x * a.nseg;
+  using G = SweepGeom<R, MODE>;
+  if (c->fast_avvels) lbm_sweep_kernel<R, true, MODE><<<dim3(blocks + 1), dim3(G::lanes), G::lds_bytes, s>>>(a);
+  else lbm_sweep_kernel<R, false, MODE><<<dim3(blocks + 1), dim3(G::lanes), G::lds_bytes, s>>>(a);
+}
+
+template <int MODE>
+void launch_sweep_m(lbm_ctx* c, bool accel_last, hipStream_t s)
+{
+  if (c->sweep_R == 4) launch_sweep_r<4, MODE>(c, accel_last, s);      // (R = 3 was measured too: 488 us/step at 8192 x 8192; not kept)
+  else launch_sweep_r<5, MODE>(c, accel_last, s);
+}
+
+void launch_sweep(lbm_ctx* c, bool accel_last, hipStream_t s)
+{
+  if (c->sweep_mode == 0) launch_sweep_m<0>(c, accel_last, s);
+  else if (c->sweep_mode == 1) launch_sweep_m<1>(c, accel_last, s);
+  else launch_sweep_m<2>(c, accel_last, s);
 }
 
 template <int T, int H>
@@ -673,6 +714,22 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
+    // streaming form of the 3-step launch (kernels/sweep.h): strips of 64 columns, segments of rows so that the launch is
+    // about one round of two blocks per CU (8192 x 8192: 128 strips x 4 segments of 2048 rows = 512 blocks).
+    // LBM_TUNE_SWEEP = R (rows per tick: 4 or 5); 0 = off (the default: measured 10-20 % slower than lbm_multi_kernel<3>)
+    const int want = tune_env("LBM_TUNE_SWEEP", 0);
+    if (want > 0 && c->multi_K == 3 && p->nx % kSTX == 0 && ny_local >= 64) {
+      const int strips = p->nx / kSTX;
+      c->sweep_mode = std::min(std::max(tune_env("LBM_TUNE_SWEEP_MODE", 2), 0), 2);
+      const int target_blocks = tune_env("LBM_TUNE_SWEEP_BLOCKS", c->sweep_mode == 0 ? 512 : 768);
+      int nseg = std::max(1, (target_blocks + strips / 2) / strips);
+      int seg_rows = (ny_local + nseg - 1) / nseg;
+      seg_rows = std::max(seg_rows, 32);
+      nseg = (ny_local + seg_rows - 1) / seg_rows;
+      c->sweep_R = want == 4 ? 4 : 5;
+      c->sweep_nseg = nseg; c->sweep_seg_rows = seg_rows;
+      c->partials_cap = std::max(c->partials_cap, 3 * strips * nseg + 1);
+    }
   } else if (c->tile_kernel) {
     c->partials_cap = std::max(c->partials_cap, kMaxTileSteps * c->n_tiles + 1);
     // up to 74 KB of dynamic LDS per block (two 9 x R x R float buffers): above the 64 KB default limit
@@ -787,9 +844,11 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     // with four ghost rows split the same way).
     const int k = next_multi_k(c, n_steps - t);
     hipEvent_t pb = prof_stamp(c, s);
-    launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, c->multi_tiles, 0, 0, /*fold=*/true, s);
+    const bool sweep = c->sweep_R > 0 && k == 3;
+    if (sweep) launch_sweep(c, /*accel_last=*/t + k < n_steps, s);
+    else launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, c->multi_tiles, 0, 0, /*fold=*/true, s);
     if (c->profile) c->prof_launches.push_back({k, pb, prof_stamp(c, s)});
-    c->n_prev = c->multi_tiles; c->n_prev_vecs = k;
+    c->n_prev = sweep ? (c->p.nx / kSTX) * c->sweep_nseg : c->multi_tiles; c->n_prev_vecs = k;
     c->parity ^= 1;
     c->cur ^= 1;
     t += k;
@@ -1262,7 +1321,8 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
-    if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_multi_kernel<%d, fast av_vels>" : "lbm_multi_kernel<%d>", c->multi_K);
+    if (c->sweep_R > 0 && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_sweep_kernel<%d, fast av_vels>" : "lbm_sweep_kernel<%d>", c->sweep_R);
+    else if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_multi_kernel<%d, fast av_vels>" : "lbm_multi_kernel<%d>", c->multi_K);
     else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_tile_kernel<%d, %d, fast av_vels>" : "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");

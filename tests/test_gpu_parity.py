@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 SMALL = ["tiny_8x3", "open_64x48", "rand_64x48", "walls_40x24", "dense_32x32", "strongaccel_32x16",
          "accelrow_blocked_32x16", "column_24x20", "wide_256x8", "tall_8x256", "synth_512x512_t100",
          "128x256_t2000", "256x256_t1000", "1024x1024_t200"]
+STRESS_KINDS = ["open", "dense", "accel_row_blocked", "strong_accel", "omega_low", "omega_high"]
 AV_EXACT_RTOL = 1e-6
 
 
@@ -591,6 +592,68 @@ def test_k_steps_per_pass_kernel(lbm, oracle, digests, monkeypatch, name, steps,
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
+@pytest.mark.parametrize("mode", ["2", "1", "0"])
+@pytest.mark.parametrize("R", [5, 4])
+@pytest.mark.parametrize("nx,ny,steps,blocks", [(128, 64, 7, 4), (64, 96, 9, 3), (256, 200, 12, 8), (192, 77, 10, 6), (512, 512, 31, 512),
+                                                 (1024, 333, 6, 48), (64, 64, 3, 1)])
+def test_sweep_kernel_shapes_and_step_counts(lbm, oracle, monkeypatch, nx, ny, steps, blocks, R, mode):
+    """lbm_sweep_kernel<R> (kernels/sweep.h: the 3-step launch as a streaming pipeline in y, strips of 64 columns, R rows
+    per tick) against the oracle, bit for bit: one strip (both x wraps in one block), several strips, segments whose rows
+    neither R nor the segment count divides, segments shorter than the pipeline is deep, step counts with 1-, 2- and 4-step
+    tails (those launches are lbm_multi_kernel's), repeated runs, obstacles on the ring columns, the accelerate row."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_SWEEP", str(R))
+    monkeypatch.setenv("LBM_TUNE_SWEEP_BLOCKS", str(blocks))
+    monkeypatch.setenv("LBM_TUNE_SWEEP_MODE", mode)                # storage form of the pipeline: kernels/sweep.h SweepGeom
+    p = lbm.Params(nx, ny, steps + 4, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.04, nx + 3 * ny + R, False)
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"] == f"lbm_sweep_kernel<{R}>"
+    av = np.concatenate([s.run(steps), s.run(4)])
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps + 4, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("kind", STRESS_KINDS)
+def test_sweep_kernel_rare_paths(lbm, oracle, monkeypatch, kind):
+    """The stress decks (no obstacle anywhere, every second cell blocked, row ny-2 walled off, an acceleration that fails
+    the positivity test, relaxation at both ends of the range) through lbm_sweep_kernel<5>, two segments."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_SWEEP", "5")
+    monkeypatch.setenv("LBM_TUNE_SWEEP_BLOCKS", "8")
+    for nx, ny in ((256, 64), (448, 112)):
+        if nx % 64:
+            continue
+        p, obst = _stress_deck(lbm, kind, nx, ny)
+        s = lbm.Simulation(p, obst)
+        assert s.partition.describe()["kernel"] == "lbm_sweep_kernel<5>"
+        av = np.concatenate([s.run(29), s.run(11)])
+        cells = s.local_cells()
+        s.close()
+        ref_cells, _, ref_exact = oracle.run(p, obst, 40, nthreads=4)
+        assert np.array_equal(bits(cells), bits(ref_cells)), (kind, nx, ny)
+        assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("name", ["128x128", "1024x1024"])
+def test_sweep_kernel_on_shipped_decks(lbm, digests, tmp_path, monkeypatch, name):
+    """Whole shipped decks (40 000 / 20 000 steps) through lbm_sweep_kernel<5>: final_state.dat is the reference binary's file."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_SWEEP", "5")
+    p, obst, free = load_case(lbm, digests, name)
+    sim = lbm.Simulation(p, obst)
+    assert sim.partition.describe()["kernel"] == "lbm_sweep_kernel<5>"
+    av = sim.run()
+    sim.write_values(av, str(tmp_path))
+    sim.close()
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    steps = np.asarray(digests[name]["av_sample_steps"])
+    assert np.allclose(av[steps], digests[name]["av_sample_values"], rtol=4e-3 if name == "1024x1024" else 5e-4)
+
+
 @pytest.mark.parametrize("steps", [1, 2, 4, 5, 7, 8, 10, 11, 13])
 @pytest.mark.parametrize("tail4", ["1", "0"])
 def test_run_lengths_that_three_does_not_divide(lbm, oracle, digests, monkeypatch, steps, tail4):
@@ -666,7 +729,7 @@ def _stress_deck(lbm, kind, nx, ny):
     return lbm.Params(nx, ny, 40, 8, density, accel, omega), obst
 
 
-STRESS = ["open", "dense", "accel_row_blocked", "strong_accel", "omega_low", "omega_high"]
+STRESS = STRESS_KINDS
 
 
 @pytest.mark.parametrize("K", [2, 3, 4])
