@@ -566,12 +566,17 @@ def main() -> int:
 
     def check_against_single_gpu(sim, p, obst, av_last, steps_done):
         """The partitioned run against ONE GPU doing the whole grid, bit for bit: 64-bit digest of this rank's
-        rows (lbm_state_checksum) and the last run's av_vels — the multi-GPU parity test, run where the GPUs are."""
-        y0, y1 = sim.partition.y0, sim.partition.y0 + sim.partition.ny_local
-        digest, av_ref = single_gpu_reference(p, obst, steps_done, y0, y1, len(av_last))
-        same = sim.partition.checksum() == digest
-        av_err = float(np.max(np.abs(av_last.astype(np.float64) - av_ref.astype(np.float64)) / av_ref.astype(np.float64))) if len(av_last) else 0.0
-        return bool(same and av_err < 1e-6), same, av_err
+        rows (lbm_state_checksum) and the last run's av_vels — the multi-GPU parity test, run where the GPUs are.
+        Never raises (a failure on one rank must not leave the others alone in the next collective)."""
+        try:
+            y0, y1 = sim.partition.y0, sim.partition.y0 + sim.partition.ny_local
+            digest, av_ref = single_gpu_reference(p, obst, steps_done, y0, y1, len(av_last))
+            same = sim.partition.checksum() == digest
+            av_err = float(np.max(np.abs(av_last.astype(np.float64) - av_ref.astype(np.float64)) / av_ref.astype(np.float64))) if len(av_last) else 0.0
+            return bool(same and av_err < 1e-6), same, av_err
+        except (lbm.LbmError, ValueError, FloatingPointError) as e:
+            sys.stderr.write(f"bench.py: rank {rank}: parity check could not run: {e}\n")
+            return False, False, float("nan")
 
     verify_on = partitioned and not args.no_verify
 
@@ -602,14 +607,23 @@ def main() -> int:
     def timed(sim, steps: int, reps: int):
         """reps x (barrier + device sync; EXACTLY `steps` steps + the reduction; device sync) -> per-rep seconds, MAX over
         ranks; last av_vels.  The barrier that closes one bracket is the next repetition's: an NCCL barrier inside the
-        region would add its own ~0.1 ms to a 1 ms region of steps."""
-        times, av = [], None
+        region would add its own ~0.1 ms to a 1 ms region of steps.  A rank whose run fails keeps meeting the others at
+        the barriers of the remaining repetitions, then every rank raises together."""
+        times, av, err = [], None, None
         for _ in range(max(1, reps)):
             sync_all()
+            if err is not None:
+                times.append(0.0)
+                continue
             t0 = time.perf_counter()
-            av = sim.run(steps)
+            try:
+                av = sim.run(steps)
+            except lbm.LbmError as e:
+                err = str(e)
             torch.cuda.synchronize()                      # this rank's device work is complete: the reduction made it wait
             times.append(time.perf_counter() - t0)        # for every rank's sums
+        if not agree(err is None):
+            raise lbm.LbmError(err or "the run failed on another rank")
         return max_over_ranks(times), av
 
     # ---- headline ----------------------------------------------------------------------------------------------
@@ -654,6 +668,7 @@ def main() -> int:
     launch_profile, phases = None, None
     if not args.no_phases:
         stage("profiled repetition")
+        mine, perr = None, None
         try:
             if not partitioned:
                 sim.partition.set_profile(True)
@@ -668,18 +683,22 @@ def main() -> int:
                 mine = sim._p2p.phases()
                 sim._p2p.set_profile(False)
                 steps_done += args.steps
-                every = gather(mine)
-                names = list(mine)
-                phases = {"unit": "us (macro_steps: a count)", "steps": args.steps,
-                          "max_over_ranks": {n: max(r[n] for r in every) for n in names},
-                          "mean_over_ranks": {n: sum(r[n] for r in every) / len(every) for n in names},
-                          "per_rank": every,
-                          "note": "one extra repetition with HIP timing events around every launch (lbm_p2p_set_profile): setup = run "
-                                  "start -> first step kernel; macro_step_steady = interior launch to interior launch without the first "
-                                  "and last macro-step; push_* = the push kernel INCLUDING its wait for both neighbours' rows; reduce = "
-                                  "last step kernel -> global sums in host memory; host_overhead = wall time of the call - device span"}
         except lbm.LbmError as e:
-            return fail(f"profiled run: {e}")
+            perr = str(e)
+        if not agree(perr is None):                       # every rank leaves together
+            return fail(f"profiled run: {perr or 'failed on another rank'}")
+        if mine is not None:
+            every = gather(mine)
+            names = list(mine)
+            phases = {"unit": "us (macro_steps: a count)", "steps": args.steps,
+                      "max_over_ranks": {n: max(r[n] for r in every) for n in names},
+                      "mean_over_ranks": {n: sum(r[n] for r in every) / len(every) for n in names},
+                      "per_rank": every,
+                      "note": "one extra repetition with HIP timing events around every launch (lbm_p2p_set_profile; the events stretch "
+                              "the run by ~10 %): setup = run start -> first step kernel; macro_step_steady = interior launch to interior "
+                              "launch without the first and last macro-step; push_* = the push kernel INCLUDING its wait for both "
+                              "neighbours' rows; reduce = last step kernel -> global sums in host memory; host_overhead = wall time of "
+                              "the call - device span"}
 
     verify = None
     if verify_on:
