@@ -73,7 +73,7 @@ def run_partitions(p, obst, size, steps, kstep):
 
 
 KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_MULTI_TILE",
-         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE"]
+         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_SWEEP", "LBM_TUNE_SWEEP_MODE", "LBM_TUNE_SWEEP_BLOCKS"]
 
 
 def main(argv=None) -> int:
@@ -96,7 +96,7 @@ def fuzz(a) -> int:
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        kind = rng.choice(["multi", "tile", "ring", "parts", "parts1", "forms"])
+        kind = rng.choice(["multi", "tile", "ring", "parts", "parts1", "forms", "sweep"])
         flags_fast = 0
         if kind == "forms":
             # the one-step kernels among themselves: one cell per lane / four cells per lane / LDS-staged, with and
@@ -111,6 +111,11 @@ def fuzz(a) -> int:
             else:
                 env["LBM_TUNE_NARROW_MAX"] = "0"
                 flags_fast = {"lds": lbm._capi.FLAG_KERNEL_LDS, "nt": lbm._capi.FLAG_NT_STORES, "no_nt": lbm._capi.FLAG_NO_NT_STORES}[form]
+        elif kind == "sweep":
+            # lbm_sweep_kernel<R> in its three storage modes: strips of 64 columns, any ny >= 64, any number of segments
+            nx, ny = 64 * int(rng.integers(1, 9 * a.scale)), int(rng.integers(64, 300 * a.scale))
+            env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_SWEEP": str(rng.choice([4, 5])), "LBM_TUNE_SWEEP_MODE": str(rng.choice([0, 1, 2])),
+                   "LBM_TUNE_SWEEP_BLOCKS": str(int(rng.integers(1, 40)))}
         elif kind == "tile":
             T = int(rng.choice([8, 16]))
             nx, ny = T * int(rng.integers(1, 20)), T * int(rng.integers(1, 20))
@@ -123,7 +128,8 @@ def fuzz(a) -> int:
             ny = int(rng.integers(32, 300 * a.scale))
             K = int(rng.integers(1, 5))
             env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K),
-                   "LBM_TUNE_MULTI_TILE": str(rng.choice([32, 64])), "LBM_P2P_SCHEDULE": str(rng.choice(["edge", "serial"]))}
+                   "LBM_TUNE_MULTI_TILE": str(rng.choice([32, 64])), "LBM_P2P_SCHEDULE": str(rng.choice(["edge", "serial"])),
+                   "LBM_TUNE_MACRO_GHOST": str(rng.choice([0, 4]))}          # 0 -> K ghost rows (tails of 1 and 2 steps), 4 -> four at any K (3s and 4s at K = 3; more ghost rows than steps otherwise)
         steps = int(rng.integers(1, 40))
         dens = float(rng.choice([0.0, 0.002, 0.05, 0.3]))
         p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])), float(rng.choice([0.7, 1.3, 1.85, 1.97])))

@@ -1346,3 +1346,39 @@ def test_fast_av_vels_flag_against_the_oracle(lbm, oracle, digests, monkeypatch,
     assert np.array_equal(bits(cells), bits(ref_cells))
     assert np.max(np.abs(av_f - ref_exact) / ref_exact) < AV_EXACT_RTOL
     assert np.max(np.abs(av_f.astype(np.float64) - av_e) / av_e) < 1e-6
+
+
+def test_launch_profile_and_ring_phases(lbm, digests, monkeypatch):
+    """The profiling entry points behind bench.py's `roofline` and `phases` (the reference's MPI_Pcontrol("mainloop") region,
+    d2q9-bgk.c:275-277,404-406): lbm_set_profile / lbm_launch_profile name every step-kernel launch of lbm_run with the steps it
+    advanced — 20 steps at K = 3 are 4 + 4 + 3 + 3 + 3 + 3 — and their durations add up to the run's kernel span;
+    lbm_p2p_set_profile / lbm_p2p_phases account for a ring run's wall time.  Profiling must not change a single bit."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
+    plain, prof = lbm.Simulation(p, obst), lbm.Simulation(p, obst)
+    prof.partition.set_profile(True)
+    av_a, av_b = plain.run(20), prof.run(20)
+    launches = prof.partition.launch_profile()
+    span_ms, n = prof.partition.last_run_kernel_ms()
+    assert [k for k, _ in launches] == [4, 4, 3, 3, 3, 3] and n == 6
+    assert all(us > 0 for _, us in launches) and 0.5 < sum(us for _, us in launches) / (span_ms * 1e3) < 1.5
+    assert np.array_equal(av_a, av_b) and np.array_equal(bits(plain.local_cells()), bits(prof.local_cells()))
+    prof.partition.set_profile(False)
+    prof.run(7)
+    assert prof.partition.launch_profile() == []                       # off again: nothing recorded
+    plain.close(); prof.close()
+    for schedule in ("edge", "serial"):
+        monkeypatch.setenv("LBM_P2P_SCHEDULE", schedule)
+        ring = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange="p2p", strict=True)
+        with pytest.raises(lbm.LbmError, match="no profiled run"):
+            ring._p2p.phases()
+        ring._p2p.set_profile(True)
+        av_r = ring.run(20)
+        ph = ring._p2p.phases()
+        assert np.max(np.abs(av_r - av_a) / av_a) < AV_EXACT_RTOL
+        k = ring.partition.macro_steps
+        assert ph["macro_steps"] == (6 if k == 3 else 5)                 # 4 + 4 + 3 + 3 + 3 + 3, or 5 x 4 (512 x 512: K = 4)
+        assert ph["host_total"] >= ph["device_span"] > 0 and abs(ph["setup"] + ph["steps"] + ph["reduce"] - ph["device_span"]) < 0.05 * ph["device_span"] + 5.0
+        assert ph["interior_avg"] > 0 and ph["push_first"] > 0 and ph["push_avg"] > 0 and (ph["edge_avg"] > 0) == (schedule == "edge")
+        assert abs(ph["host_overhead"] - (ph["host_total"] - ph["device_span"])) < 1e-6
+        ring.close()
