@@ -29,7 +29,20 @@ namespace {
 #ifndef LBM_MWAVES         // waves per SIMD the K <= 3 kernels are compiled for (register budget 512 / LBM_MWAVES)
 #define LBM_MWAVES 6
 #endif
-constexpr int kMTX = 64, kMTY = LBM_MTY, kMLanes = LBM_MLANES, kMaxMultiSteps = 4;
+#ifndef LBM_MTY4           // tile height of the 4-step instantiation
+#define LBM_MTY4 13
+#endif
+constexpr int kMTX = 64, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMLanes = LBM_MLANES, kMaxMultiSteps = 4;
+// Tile height by steps per launch.  K <= 3: 64 x 16 tiles (K = 3: 72 x 20 frame, 51.8 KB, three blocks per CU).  K = 4 on
+// 64 x 16 tiles needs a 76 x 22 frame = 60 KB: two blocks per CU, and measured 353 - 363 us/step at 8192 x 8192 against 341
+// - 347 for K = 3.  On 64 x 13 tiles its frame is 76 x 19 = 52.0 KB — three blocks per CU again (3 x 52 962 B of 160 KB) —
+// and although a tile then recomputes 1.36 x its cells per step instead of 1.31 x, the launch moves 24.6 B per cell-step
+// instead of 26.9 with one kernel boundary per four steps: us/step for K = 3 / K = 4 on 64 x 12 / 64 x 13 / 64 x 11 tiles —
+// 8192 x 8192 346.6 / 322.8 / 324.0 / 336.4, 4096 x 4096 87.2 / 80.6 / 78.4 / 85.6, 2048 x 2048 24.0 / 23.3 / 21.6 / 23.8,
+// 1024 x 1024 8.16 / 7.50 / 7.07 / 7.55, 8192 x 1024 53.0 / 45.5 / 43.5 / 46.6, 512 x 512 3.11 / 3.44 / 3.45 / 3.28
+// (profiles/r03/ab_k3_k4.txt).  K = 4 is lbm_run's choice from 1 M cells up and every K-step partition's.
+// (K = 3 on shorter tiles loses: 64 x 12 367, 64 x 10 at four blocks per CU 347 against 341.)
+constexpr int multi_ty(int k) { return k >= 4 ? kMTY4 : kMTY; }
 // Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:
 // twice the tiles, each with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
 constexpr int kMTXNarrow = 32;
@@ -46,8 +59,9 @@ constexpr int kMTXNarrow = 32;
 
 template <int K, int TX = kMTX>
 struct MultiGeom {
+  static constexpr int TY = multi_ty(K);                            // owned rows of a tile
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
-  static constexpr int W = TX + 2 * EX, H = kMTY + 2 * EY;          // LDS frame
+  static constexpr int W = TX + 2 * EX, H = TY + 2 * EY;            // LDS frame
   static constexpr int cells = W * H;
   static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64) + (K >= 2 ? cells / 2 : 0);   // + a flag byte per x-pair
 };
@@ -95,10 +109,10 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
 template <int K, bool FAST, int TX>   // FAST: float sum|u| terms (LBM_FLAG_FAST_AVVELS), see finish_pair; TX: tile width
-__global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_kernel(const MultiArgs a)
+__global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 160 * 1024) ? LBM_MWAVES : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, TX>;
-  constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kWaves = kMLanes / 64;
+  constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kWaves = kMLanes / 64, TY = G::TY;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
   // per x-pair of the frame, written by sub-step 1 and read by the in-LDS sub-steps (which then need no
@@ -137,7 +151,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
   const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int x0 = tx * TX;
-  const int sy0 = a.ghost + ty * kMTY;              // storage row of the tile's first owned row
+  const int sy0 = a.ghost + ty * TY;              // storage row of the tile's first owned row
   const int nx = a.nx;
   const int rows_storage = a.rows_owned + 2 * a.ghost;
   const int tile_row_base = sy0 * nx;               // block-uniform: a scalar multiply
@@ -150,7 +164,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
   // does the LDS frame of this tile meet the global accelerate row ny-2 at all ?  (block-uniform)
   bool tile_accel;
   {
-    int d = (a.accel_row - (a.y0_global + ty * kMTY - EY)) % a.ny_global;     // frame row 0 is global row y0 + ty*16 - EY
+    int d = (a.accel_row - (a.y0_global + ty * TY - EY)) % a.ny_global;     // frame row 0 is global row y0 + ty*TY - EY
     if (d < 0) d += a.ny_global;
     tile_accel = d < G::H || a.ny_global < G::H;
   }
@@ -165,11 +179,11 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
   {
     const int ey = ksteps - 1, ex = 2 * ey;
     const int wp = (TX + 2 * ex) / 2;                                 // pairs per region row
-    const int np = wp * (kMTY + 2 * ey);
+    const int np = wp * (TY + 2 * ey);
     // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
     // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
-    const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + kMTY + EY + 1 <= rows_storage &&
-                       sy0 + kMTY <= a.ghost + a.rows_owned;
+    const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + TY + EY + 1 <= rows_storage &&
+                       sy0 + TY <= a.ghost + a.rows_owned;
 #pragma unroll 1
     for (int i = tid; i < np; i += kMLanes) {
       const int ry = i / wp, rp = i - ry * wp;
@@ -225,7 +239,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
       f2 out[9];
       // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
       // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
-      const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + kMTY &&
+      const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
                          (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
@@ -252,7 +266,7 @@ __global__ void __launch_bounds__(kMLanes, K <= 3 ? LBM_MWAVES : 4) lbm_multi_ke
     auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
       const int ey = ksteps - j, ex = 2 * ey;
       const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
-      const int rows = kMTY + 2 * ey;
+      const int rows = TY + 2 * ey;
       const int rpp = kMLanes / wp;                                      // whole rows per pass
       const bool last = j == ksteps;
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written

@@ -268,6 +268,10 @@ void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, bool fast, in
   else launch_multi_kt<K, kMTX>(blocks, s, a, fast);
 }
 
+// Tiles of a launch that makes `k` steps: the tile height depends on k (kernels/multi.h multi_ty).
+int multi_tile_rows(const lbm_ctx* c, int k) { return (c->nyl + multi_ty(k) - 1) / multi_ty(k); }
+int multi_tiles_for(const lbm_ctx* c, int k) { return c->multi_tiles_x * multi_tile_rows(c, k); }
+
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
 void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t1, int n1, bool fold, hipStream_t s)
 {
@@ -279,7 +283,7 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   a.y0_global = c->y0; a.ny_global = c->p.ny;
   a.tiles_x = c->multi_tiles_x;
   a.tile_begin = t0; a.tile_count = n0; a.tile_begin2 = t1; a.tile_count2 = n1;
-  a.ntiles_total = c->multi_tiles;
+  a.ntiles_total = multi_tiles_for(c, ksteps);
   a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
   a.accel_row = c->p.ny - 2; a.accel_last = accel_last ? 1 : 0;
   a.partials_out = c->partials[c->parity];
@@ -427,15 +431,18 @@ hipError_t stream_wait(hipStream_t s)
   return hipStreamSynchronize(s);
 }
 
-// Steps of the next launch of lbm_multi_kernel when `left` steps remain: multi_K, except that at K = 3 a count that 3
-// does not divide is split into 3s and 4s where that avoids a K = 2 / K = 1 launch at the end — whole periodic grids
-// (the frame wraps) and row partitions that keep four ghost rows.  A function of (K, ghost, left) only, so every rank of
-// a partitioned run makes the same sequence of macro-steps.
+// Steps of the next launch of lbm_multi_kernel when `left` steps remain: multi_K, except that a count multi_K does not
+// divide is split into 3s and 4s where that avoids a K = 2 / K = 1 launch at the end (8192 x 8192, us per launch: K = 1 870,
+// K = 2 1000, K = 3 1050, K = 4 1290) — at K = 3: n = 3a + 4 or 3a + 8; at K = 4: n = 4a + 3, 4a + 6 or 4a + 9.  Whole periodic
+// grids (the frame wraps) and row partitions that keep four ghost rows.  A function of (K, ghost, left) only, so every
+// rank of a partitioned run makes the same sequence of macro-steps.
 int next_multi_k(const lbm_ctx* c, int left)
 {
   int k = std::min(c->multi_K, left);
   const bool room = c->self_periodic || c->ghost >= 4;
-  if (c->multi_K == 3 && room && c->multi_tail4 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
+  if (!room || !c->multi_tail4) return k;
+  if (c->multi_K == 3 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
+  if (c->multi_K == 4 && ((left % 4 == 3) || (left % 4 == 2 && left >= 6) || (left % 4 == 1 && left >= 9))) k = 3;
   return k;
 }
 
@@ -492,10 +499,12 @@ static bool macro_eligible(const lbm_params* p, int rows, unsigned flags)
 // us/step for K = 2 / 3 / 4 (one-step loop):
 //   8192x4096 rows 243 / 182 / 199   8192x2048 rows 122 / 92.6 / 103   8192x1024 rows 66.2 / 52.5 / 55.9 (116)
 //   1024x128 rows 26.1 / 18.8 / 14.7 (37)
+// Round 3: with the 4-step launch on 64 x 13 tiles (three blocks per CU, kernels/multi.h) K = 4 wins at every size — 1-rank
+// p2p rings, us/step for K = 3 / K = 4: 8192x4096 178.9 / 166.2, 8192x1024 51.3 / 48.5, 1024x128 4.40 / 4.04.
 static int macro_k_for(size_t max_cells)
 {
-  const int by_size = max_cells < (1u << 21) ? 4 : 3;
-  return std::min(std::max(tune_env("LBM_TUNE_MACRO_K", by_size), 0), kMaxMultiSteps);
+  (void)max_cells;
+  return std::min(std::max(tune_env("LBM_TUNE_MACRO_K", 4), 0), kMaxMultiSteps);
 }
 
 // Ghost rows kept on each side of a K-step partition.  One more than K at K = 3: a run whose step count 3 does not
@@ -701,7 +710,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
-    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
+    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + std::min(kMTY, kMTY4) - 1) / std::min(kMTY, kMTY4)) + 1);
   } else if (!c->tile_kernel && self_periodic && fits_u32 && p->nx < (1 << 23) &&      // (24-bit row multiplies in lbm_multi_kernel)
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
@@ -710,16 +719,19 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     //   8192x8192 500 / 360 / 405 (853-917)   2048x2048 33.5 / 25.5 / 27.4 (59)
     //   1024x1024 11.2 / 8.3 / 8.5 (13.5)   512x512 3.7 / 3.4 / 3.3 (6.3; lbm_tile_kernel 5.2)
     // K = 2 is HBM-bound, K = 4 instruction-bound at 2 blocks per CU (60 KB frames); K = 3 sits at both limits
-    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", 3), 0), kMaxMultiSteps);
+    // round 3, 4-step launch on 64 x 13 tiles: K = 3 / K = 4 8192x8192 346.6 / 324.0, 4096x4096 87.2 / 78.4, 2048x2048 24.0 / 21.6,
+    // 1024x1024 8.16 / 7.07, 512x512 3.11 / 3.45 -> K = 4 from 1 M cells up
+    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= (size_t(1) << 20) ? 4 : 3), 0), kMaxMultiSteps);
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
-    if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles + 1);
+    if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + std::min(kMTY, kMTY4) - 1) / std::min(kMTY, kMTY4)) + 1);
     // streaming form of the 3-step launch (kernels/sweep.h): strips of 64 columns, segments of rows so that the launch is
     // about one round of two blocks per CU (8192 x 8192: 128 strips x 4 segments of 2048 rows = 512 blocks).
     // LBM_TUNE_SWEEP = R (rows per tick: 4 or 5); 0 = off (the default: measured 10-20 % slower than lbm_multi_kernel<3>)
     const int want = tune_env("LBM_TUNE_SWEEP", 0);
-    if (want > 0 && c->multi_K == 3 && p->nx % kSTX == 0 && ny_local >= 64) {
+    if (want > 0 && c->multi_K >= 3 && p->nx % kSTX == 0 && ny_local >= 64) {
+      c->multi_K = 3;                                        // the sweep makes 3-step launches; tails are lbm_multi_kernel's
       const int strips = p->nx / kSTX;
       c->sweep_mode = std::min(std::max(tune_env("LBM_TUNE_SWEEP_MODE", 2), 0), 2);
       const int target_blocks = tune_env("LBM_TUNE_SWEEP_BLOCKS", c->sweep_mode == 0 ? 512 : 768);
@@ -847,9 +859,9 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     hipEvent_t pb = prof_stamp(c, s);
     const bool sweep = c->sweep_R > 0 && k == 3;
     if (sweep) launch_sweep(c, /*accel_last=*/t + k < n_steps, s);
-    else launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, c->multi_tiles, 0, 0, /*fold=*/true, s);
+    else launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/true, s);
     if (c->profile) c->prof_launches.push_back({k, pb, prof_stamp(c, s)});
-    c->n_prev = sweep ? (c->p.nx / kSTX) * c->sweep_nseg : c->multi_tiles; c->n_prev_vecs = k;
+    c->n_prev = sweep ? (c->p.nx / kSTX) * c->sweep_nseg : multi_tiles_for(c, k); c->n_prev_vecs = k;
     c->parity ^= 1;
     c->cur ^= 1;
     t += k;
@@ -1188,10 +1200,11 @@ int lbm_macro_next_steps(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run
 // after the exchange); the `interior_rows` rows between them do not.  The top edge is two tile rows
 // when the last one holds fewer owned rows than a launch makes steps (the ring of the row below then reaches the ghosts).
 struct MacroRows { int interior_rows, top_edge_rows; };
-static MacroRows macro_rows(const lbm_ctx* c)
+static MacroRows macro_rows(const lbm_ctx* c, int k)            // k = steps of the launch: the tile height follows it
 {
-  const int nty = (c->nyl + kMTY - 1) / kMTY;
-  const int last_rows = c->nyl - (nty - 1) * kMTY;
+  const int ty = multi_ty(k);
+  const int nty = (c->nyl + ty - 1) / ty;
+  const int last_rows = c->nyl - (nty - 1) * ty;
   int top = last_rows < c->ghost ? 2 : 1;                  // (ghost = the most steps a launch of this partition makes)
   top = std::min(top, nty - 1);
   return {nty - 1 - top, top};
@@ -1202,7 +1215,7 @@ int lbm_macro_interior(lbm_ctx* c, void* stream)
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_interior: not a K-step context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_interior: no steps left; call lbm_macro_prepare"); return 1; }
   const int k = macro_k(c);
-  const MacroRows r = macro_rows(c);
+  const MacroRows r = macro_rows(c, k);
   if (r.interior_rows > 0) {   // tile rows whose K-ring stays inside the owned rows
     launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * r.interior_rows, 0, 0,
                  /*fold=*/c->n_prev > 0, pick_stream(c, stream));
@@ -1217,7 +1230,7 @@ int lbm_macro_edge(lbm_ctx* c, void* stream)
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_edge: not a K-step context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_edge: no steps left; call lbm_macro_prepare"); return 1; }
   const int k = macro_k(c);
-  const MacroRows r = macro_rows(c);
+  const MacroRows r = macro_rows(c, k);
   // whichever of the two launches of a macro-step comes first folds the previous macro-step's sums
   launch_multi(c, k, c->run_done + k < c->run_steps, 0, c->multi_tiles_x, (1 + r.interior_rows) * c->multi_tiles_x,
                r.top_edge_rows * c->multi_tiles_x, /*fold=*/c->n_prev > 0, pick_stream(c, stream));
@@ -1231,7 +1244,7 @@ int lbm_macro_finish(lbm_ctx* c, void* stream)
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_finish: not a K-step context"); return 1; }
   hipStream_t s = pick_stream(c, stream);
   const int k = macro_k(c);
-  c->n_prev = c->multi_tiles;
+  c->n_prev = multi_tiles_for(c, k);
   c->n_prev_vecs = k;
   c->parity ^= 1;
   c->cur ^= 1;

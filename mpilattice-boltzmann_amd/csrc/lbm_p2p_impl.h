@@ -570,10 +570,10 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     sp_push.push_back(sp);
   }
   hipEvent_t e_steps0 = p2p_stamp(t, cs);
-  const MacroRows rows = macro_rows(c);
   int macro_steps = 0;
   for (int done = 0; done < n_steps; ++epoch, ++macro_steps) {
     const int k = next_multi_k(c, n_steps - done);             // K, or 3s and 4s (the same sequence on every rank)
+    const MacroRows rows = macro_rows(c, k);                    // (the tile height follows the steps of the launch)
     const bool more = done + k < n_steps;
     if (t->edge_stream) {
       if (rows.interior_rows > 0) {                            // :350, beside the exchange
@@ -598,7 +598,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     } else {
       P2PSpan sp;
       sp.begin = p2p_stamp(t, cs);
-      launch_multi(c, k, more, 0, c->multi_tiles, 0, 0, /*fold=*/c->n_prev > 0, cs);
+      launch_multi(c, k, more, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/c->n_prev > 0, cs);
       sp.end = p2p_stamp(t, cs);
       sp_interior.push_back(sp);
       c->n_prev = 0;
@@ -607,7 +607,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     // the next interior launch needs this macro-step's edge ROWS, not the push that follows them
     if (t->edge_stream) P2P_RUN_TRY(hipEventRecord(t->edge_done, es));
     // state flip of lbm_macro_finish (d2q9-bgk.c:376-378)
-    c->n_prev = c->multi_tiles;
+    c->n_prev = multi_tiles_for(c, k);
     c->n_prev_vecs = k;
     c->parity ^= 1;
     c->cur ^= 1;

@@ -592,6 +592,23 @@ def test_k_steps_per_pass_kernel(lbm, oracle, digests, monkeypatch, name, steps,
     assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
+@pytest.mark.parametrize("steps", [1, 2, 3, 5, 6, 7, 9, 10, 11, 13, 14])
+def test_run_lengths_that_four_does_not_divide(lbm, oracle, digests, monkeypatch, steps):
+    """lbm_run at K = 4 (64 x 13 tiles; the choice from 1 M cells up) splits a step count 4 does not divide into 4s and 3s
+    (n = 4a + 3, 4a + 6, 4a + 9): launches of different tile heights alternate inside one run, each folding the other's sums."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", "4")
+    p, obst, free = load_case(lbm, digests, "synth_512x512_t100")
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"] == "lbm_multi_kernel<4>"
+    av = np.concatenate([s.run(steps), s.run(steps)])
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, 2 * steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert av.shape == (2 * steps,) and np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
 @pytest.mark.parametrize("mode", ["2", "1", "0"])
 @pytest.mark.parametrize("R", [5, 4])
 @pytest.mark.parametrize("nx,ny,steps,blocks", [(128, 64, 7, 4), (64, 96, 9, 3), (256, 200, 12, 8), (192, 77, 10, 6), (512, 512, 31, 512),
@@ -1125,7 +1142,7 @@ def test_bench_on_two_gpus_harvests_every_part(lbm):
     assert out["variants"]["rccl_step_allreduce"]["parity_ok"] is True and out["variants"]["rccl_step_allreduce"]["step_allreduce"] is True
     sec = out["secondary"]["input_1024x1024"]
     assert sec["p2p"]["parity_ok"] is True and sec["rccl"]["parity_ok"] is True
-    assert out["phases"]["max_over_ranks"]["macro_steps"] == 6 and len(out["phases"]["per_rank"]) == 2
+    assert out["phases"]["max_over_ranks"]["macro_steps"] == 5 and len(out["phases"]["per_rank"]) == 2
 
 
 @pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge")])
@@ -1192,14 +1209,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0 and "truncated" not in out
-    assert out["config"]["loop"] == "p2p" and out["config"]["macro_k"] == 3 and "ipc" in out["config"]["p2p"]
+    assert out["config"]["loop"] == "p2p" and out["config"]["macro_k"] == 4 and "ipc" in out["config"]["p2p"]
     assert out["parity_check"]["ok"] is True and out["exchange_attempts"][0] == {"exchange": "p2p", "ok": True}
     assert out["launch_attempts"][0]["returncode"] == 0
     # what one multi-rank invocation harvests beside the headline: phases of a profiled repetition,
     # the RCCL variants (here: recorded as not usable, the two ranks share this box's one GPU — not a crash), and
     # BASELINE.json config 4, the shipped 1024 x 1024 deck on the same ranks
     ph = out["phases"]
-    assert len(ph["per_rank"]) == 2 and ph["max_over_ranks"]["macro_steps"] == 6            # 20 = 4 + 4 + 3 + 3 + 3 + 3
+    assert len(ph["per_rank"]) == 2 and ph["max_over_ranks"]["macro_steps"] == 5            # 20 = 5 x 4
     for name in ("host_total", "setup", "steps", "reduce", "macro_step_avg", "interior_avg", "push_first", "push_avg", "host_overhead"):
         assert ph["max_over_ranks"][name] > 0, name
     for name in ("rccl", "rccl_step_allreduce"):
@@ -1314,7 +1331,7 @@ def test_fast_av_vels_flag_on_the_shipped_decks(lbm, digests, tmp_path, monkeypa
     monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")                     # the small decks through lbm_multi_kernel too
     p, obst, free = load_case(lbm, digests, name)
     sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FAST_AVVELS)
-    assert sim.partition.describe()["kernel"] == "lbm_multi_kernel<3, fast av_vels>"
+    assert sim.partition.describe()["kernel"] == ("lbm_multi_kernel<4, fast av_vels>" if name == "1024x1024" else "lbm_multi_kernel<3, fast av_vels>")
     av = sim.run()
     sim.write_values(av, str(tmp_path))
     sim.close()

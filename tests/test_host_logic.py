@@ -170,11 +170,11 @@ def test_rank_layout_is_one_decision_for_all_ranks(lbm):
         k = lays[0]["macro_k"]
         if size == 1:
             assert k == 0                                            # a whole periodic grid needs no ghost rows ...
-            assert lbm.rank_layout(p, 1, 0, lbm._capi.FLAG_FORCE_HALO)["macro_k"] == (3 if nx * ny >= 1 << 21 else 4)   # ... a 1-rank ring does
+            assert lbm.rank_layout(p, 1, 0, lbm._capi.FLAG_FORCE_HALO)["macro_k"] == 4   # ... a 1-rank ring does (K = 4 at every size since round 3)
         elif min(nyl) < 32 or nx % 2 or nx < 128 and nx % 64:
             assert k == 0                                            # one ineligible rank puts EVERY rank in one-step mode
         else:
-            assert k == (4 if nx * max(nyl) < 1 << 21 else 3)
+            assert k == 4                                            # (round 2: 3 above 2 M cells per rank)
         assert all(l["macro_k"] == 0 for l in (lbm.rank_layout(p, size, r, lbm._capi.FLAG_ONE_STEP) for r in range(size)))
     p = lbm.Params(1024, 190, 10, 10, 0.1, 0.005, 1.85)
     assert [lbm.rank_layout(p, 6, r)["macro_k"] for r in range(6)] == [0] * 6       # ranks 4, 5 own 31 rows
