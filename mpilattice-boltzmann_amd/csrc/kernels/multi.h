@@ -40,7 +40,7 @@ constexpr int kMTX = 64, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMLanes = LBM_MLANES,
 // instead of 26.9 with one kernel boundary per four steps: us/step for K = 3 / K = 4 on 64 x 12 / 64 x 13 / 64 x 11 tiles —
 // 8192 x 8192 346.6 / 322.8 / 324.0 / 336.4, 4096 x 4096 87.2 / 80.6 / 78.4 / 85.6, 2048 x 2048 24.0 / 23.3 / 21.6 / 23.8,
 // 1024 x 1024 8.16 / 7.50 / 7.07 / 7.55, 8192 x 1024 53.0 / 45.5 / 43.5 / 46.6, 512 x 512 3.11 / 3.44 / 3.45 / 3.28
-// (profiles/r03/ab_k3_k4.txt).  K = 4 is lbm_run's choice from 1 M cells up and every K-step partition's.
+// (profiles/r03/ab_k3_k4.txt).  K = 4 is lbm_run's choice from 768 x 768 cells up and every K-step partition's.
 // (K = 3 on shorter tiles loses: 64 x 12 367, 64 x 10 at four blocks per CU 347 against 341.)
 constexpr int multi_ty(int k) { return k >= 4 ? kMTY4 : kMTY; }
 // Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:

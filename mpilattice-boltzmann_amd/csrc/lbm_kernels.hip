@@ -720,8 +720,9 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     //   1024x1024 11.2 / 8.3 / 8.5 (13.5)   512x512 3.7 / 3.4 / 3.3 (6.3; lbm_tile_kernel 5.2)
     // K = 2 is HBM-bound, K = 4 instruction-bound at 2 blocks per CU (60 KB frames); K = 3 sits at both limits
     // round 3, 4-step launch on 64 x 13 tiles: K = 3 / K = 4 8192x8192 346.6 / 324.0, 4096x4096 87.2 / 78.4, 2048x2048 24.0 / 21.6,
-    // 1024x1024 8.16 / 7.07, 512x512 3.11 / 3.45 -> K = 4 from 1 M cells up
-    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= (size_t(1) << 20) ? 4 : 3), 0), kMaxMultiSteps);
+    // 1536x1536 14.2 / 13.8, 1024x1024 8.16 / 7.07, 768x768 5.39 / 4.63, 1024x512 4.51 / 4.72, 512x1024 4.39 / 4.62, 640x640 4.01 / 4.13,
+    // 512x512 3.11 / 3.45 -> K = 4 from 768 x 768 cells up (profiles/r03/ab_k3_k4.txt, ab_k3_k4_threshold.txt)
+    c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= size_t(768) * 768 ? 4 : 3), 0), kMaxMultiSteps);
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);

@@ -23,7 +23,7 @@ for wl in 8192x4096 8192x1024 1024x128; do
   done
 done
 # the driver's timed region (20 steps) on the 8-GPU share: what a run costs beyond its steps
-python bench.py --ring --exchange p2p --workload 8192x1024 --steps 20 --warmup 5 --reps 9 --no-cpu-baseline --no-variants --no-secondary > $OUT/ring_8192x1024_p2p_s20.json; short $OUT/ring_8192x1024_p2p_s20.json
+python bench.py --ring --exchange p2p --workload 8192x1024 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-secondary > $OUT/ring_8192x1024_p2p_s20.json; short $OUT/ring_8192x1024_p2p_s20.json
 python scripts/ab_ring.py --grid 8192x1024 --steps 20 --rounds 60 LBM_SPIN_WAIT_US=0 LBM_SPIN_WAIT_US=4000 2>&1 | tail -2 | tee $OUT/ab_ring_spin_8192x1024_s20.txt
 python bench.py --ring --exchange rccl --step-allreduce --workload 8192x1024 --steps 300 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > $OUT/ring_8192x1024_rccl_step_allreduce.json; short $OUT/ring_8192x1024_rccl_step_allreduce.json
 python bench.py --ring --exchange rccl --step-allreduce --workload 1024x128 --steps 3000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > $OUT/ring_1024x128_rccl_step_allreduce.json; short $OUT/ring_1024x128_rccl_step_allreduce.json
