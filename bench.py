@@ -604,24 +604,42 @@ def main() -> int:
             sim = None
         return sim, (None if ok else (note or "failed on another rank"))
 
-    def timed(sim, steps: int, reps: int):
+    settle_log: dict = {}
+
+    def timed(sim, steps: int, reps: int, what: str = "headline"):
         """reps x (barrier + device sync; EXACTLY `steps` steps + the reduction; device sync) -> per-rep seconds, MAX over
         ranks; last av_vels.  The barrier that closes one bracket is the next repetition's: an NCCL barrier inside the
         region would add its own ~0.1 ms to a 1 ms region of steps.  A rank whose run fails keeps meeting the others at
-        the barriers of the remaining repetitions, then every rank raises together."""
+        the barriers of the remaining repetitions, then every rank raises together.
+
+        Short regions are preceded by UNTIMED repetitions of the same region until ~60 ms of back-to-back runs have passed
+        (`timing.settle_reps`): the part needs that long to settle — the same for a 6 ms region on one GPU (7.7, 6.9, 6.6,
+        6.4, 6.4 ... ms) and a 1 ms region of an 8-GPU rank's share (1.33, 1.05, 1.10, 1.14, 1.12, 1.08, 1.06, 1.04 ... 0.98 ms
+        after twenty) — and W = 5 warm-up steps are 0.3 - 1.6 ms.  The count is agreed on by the ranks from the first run."""
         times, av, err = [], None, None
-        for _ in range(max(1, reps)):
+
+        def one():
+            nonlocal av, err
             sync_all()
             if err is not None:
-                times.append(0.0)
-                continue
+                return 0.0
             t0 = time.perf_counter()
             try:
                 av = sim.run(steps)
             except lbm.LbmError as e:
                 err = str(e)
             torch.cuda.synchronize()                      # this rank's device work is complete: the reduction made it wait
-            times.append(time.perf_counter() - t0)        # for every rank's sums
+            return time.perf_counter() - t0               # for every rank's sums
+
+        settle = 0
+        if steps <= 50 and reps > 1:
+            first = max_over_ranks([one()])[0]
+            settle = 1 + (0 if first <= 0 else int(min(63, max(0, round(0.06 / first)))))
+            for _ in range(settle - 1):
+                one()
+        settle_log[what] = settle
+        for _ in range(max(1, reps)):
+            times.append(one())
         if not agree(err is None):
             raise lbm.LbmError(err or "the run failed on another rank")
         return max_over_ranks(times), av
@@ -661,7 +679,7 @@ def main() -> int:
     assert av.shape == (args.steps,) and np.all(np.isfinite(av)) and np.all(av > 0)
     desc = sim.partition.describe()
     what = sim.describe()
-    steps_done = args.warmup + args.steps * max(1, args.reps)
+    steps_done = args.warmup + args.steps * (max(1, args.reps) + settle_log.get("headline", 0))
 
     # one more repetition with HIP events around every launch: the per-kernel launch durations behind `roofline`
     # (single GPU) or where a rank's run goes (`phases`, peer-to-peer loop).  Not timed: the events perturb the schedule.
@@ -750,8 +768,11 @@ def main() -> int:
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny, "partitioning": part_txt,
                        "loop": what["loop"], "macro_k": what["macro_k"], "rccl_nranks": what["rccl_nranks"], "p2p": what["p2p"],
                        "step_allreduce": what["step_allreduce"], "kernel": desc["kernel"], "control_plane": backend if world > 1 else None},
-            "timing": {"reps": len(times), "statistic": "median over reps of (max over ranks of the time of EXACTLY `steps` steps): every rank starts behind a barrier + "
-                                    "device synchronise and stops its clock when its own device work, which ends with the global reduction, is complete",
+            "timing": {"reps": len(times), "settle_reps": settle_log.get("headline", 0),
+                       "statistic": "median over reps of (max over ranks of the time of EXACTLY `steps` steps): every rank starts behind a barrier + "
+                                    "device synchronise and stops its clock when its own device work, which ends with the global reduction, is complete; "
+                                    "regions of <= 50 steps are preceded by `settle_reps` untimed repetitions of the same region (~60 ms of back-to-back runs: "
+                                    "the part's clocks and caches take that long to settle whatever the region length)",
                        "ms_per_rep": [t * 1e3 for t in times]},
             "pct_hbm_roofline": 100.0 * mlups / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_CELL / 1e6),
             "roofline": roof,
@@ -771,7 +792,7 @@ def main() -> int:
         alt = lbm.Simulation(params, obstacles, device=local_rank, flags=flags | lbm._capi.FLAG_FAST_AVVELS)
         if "fast av_vels" in alt.partition.describe()["kernel"]:
             alt.run(args.warmup)
-            talt, av_alt = timed(alt, args.steps, args.reps)
+            talt, av_alt = timed(alt, args.steps, args.reps, what="fast_av_vels")
             med = float(np.median(talt))
             variants = {"fast_av_vels": {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
                                          "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt.astype(np.float64) - av) / av)),
@@ -806,8 +827,8 @@ def main() -> int:
             vs, note = set_up(params, obstacles, mode, step_allreduce, args.warmup, flags)
             if vs is None:
                 return {"error": note}
-            vt, vav = timed(vs, args.steps, args.reps)
-            done = args.warmup + args.steps * max(1, args.reps)
+            vt, vav = timed(vs, args.steps, args.reps, what=f"variant {mode} {step_allreduce}")
+            done = args.warmup + args.steps * (max(1, args.reps) + settle_log.get(f"variant {mode} {step_allreduce}", 0))
             res = {"value": nx * ny * args.steps / float(np.median(vt)) / 1e6, "unit": "MLUPS", "ms_per_step": float(np.median(vt)) / args.steps * 1e3,
                    "ms_per_rep": [t * 1e3 for t in vt], **{k2: v for k2, v in vs.describe().items() if k2 in ("loop", "macro_k", "rccl_nranks", "step_allreduce")}}
             if verify_on:
@@ -843,7 +864,7 @@ def main() -> int:
             if s4 is None:
                 res[mode] = {"error": note}
                 continue
-            t4, av4 = timed(s4, n4, 1)
+            t4, av4 = timed(s4, n4, 1, what="secondary")
             r4 = {"seconds": t4[0], "us_per_step": t4[0] / n4 * 1e6, "value": p4.nx * p4.ny * n4 / t4[0] / 1e6, "unit": "MLUPS",
                   **{k2: v for k2, v in s4.describe().items() if k2 in ("loop", "macro_k", "p2p", "rccl_nranks")}}
             if verify_on:
