@@ -100,8 +100,8 @@ int lbm_create_global(lbm_ctx** ctx, const lbm_params* p, int free_cells, const 
  * size threshold would then disagree about message sizes and exchange cadence.  A multi-rank run
  * therefore asks lbm_rank_layout: it applies the reference's decomposition (d2q9-bgk.c:834-862) and
  * derives ONE mode and ONE K for all ranks from nx, ny, nranks and flags alone (every rank eligible:
- * min rows >= 32, nx a multiple of 64 or even >= 128, LBM_FLAG_ONE_STEP clear; K = 4 when the largest
- * partition has < 2 M cells, else 3; LBM_TUNE_MACRO_K overrides) — the same answer on every rank by
+ * min rows >= 32, nx a multiple of 64 or even >= 128, LBM_FLAG_ONE_STEP clear; K = 4 — four-step launches on
+ * 64 x 13 tiles; LBM_TUNE_MACRO_K overrides) — the same answer on every rank by
  * construction.  macro_k == 0 means one-step mode (lbm_step_*). */
 typedef struct lbm_layout {
   int y0, ny_local;                 /* rows [y0, y0+ny_local) of the global grid belong to the rank */

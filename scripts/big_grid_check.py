@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ad-hoc maximum-size check (not part of the suite: ~45 GB of device state per context):
 a grid whose plane exceeds 2 GiB, so that the multi kernel's 32-bit byte offsets use bit 31.
-lbm_multi_kernel<3> (7 steps = 3 + 3 + 1) against the one-step kernel on the same deck, bit for bit.
+lbm_multi_kernel<3> (7 steps = 3 + 4) and <4> (7 = 4 + 3) against the one-step kernel on the same deck, bit for bit.
 
     python scripts/big_grid_check.py [--grid 16384x36864]"""
 import argparse
@@ -30,7 +30,7 @@ obst[:, 0] = obst[:, -1] = 1
 print(f"deck {nx}x{ny}: {nx * ny / 2**30:.2f} Gi cells, plane {nx * ny * 4 / 2**30:.2f} GiB ({time.time() - t:.0f} s)", flush=True)
 
 out = {}
-for name, k in (("multi", "3"), ("one-step", "0")):
+for name, k in (("multi", "3"), ("multi4", "4"), ("one-step", "0")):
     os.environ["LBM_TUNE_MULTI_K"] = k
     s = lbm.Simulation(p, obst)
     d = s.partition.describe()
@@ -41,11 +41,13 @@ for name, k in (("multi", "3"), ("one-step", "0")):
     s.close()
 same = True
 step = 1 << 24
-a0, a1 = out["multi"][0].reshape(-1), out["one-step"][0].reshape(-1)
-for i in range(0, a0.size, step):
-    if not np.array_equal(a0[i:i + step], a1[i:i + step]):
-        same = False
-        print("cells differ in chunk", i // step, flush=True)
-        break
-print("cells bit-identical:", same, " av rel diff:", float(np.max(np.abs(out["multi"][1] - out["one-step"][1]) / out["one-step"][1])))
+a1 = out["one-step"][0].reshape(-1)
+for which in ("multi", "multi4"):
+    a0 = out[which][0].reshape(-1)
+    for i in range(0, a0.size, step):
+        if not np.array_equal(a0[i:i + step], a1[i:i + step]):
+            same = False
+            print(which, "cells differ in chunk", i // step, flush=True)
+            break
+    print(which, "cells bit-identical:", same, " av rel diff:", float(np.max(np.abs(out[which][1] - out["one-step"][1]) / out["one-step"][1])))
 sys.exit(0 if same else 1)
