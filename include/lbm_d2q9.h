@@ -72,6 +72,14 @@ int lbm_read_obstacles(const char* obstaclefile, int nx, int ny, int* obstacles,
 /* Row decomposition rule of d2q9-bgk.c:834-862 (last rank keeps >= 3 rows). */
 int lbm_decompose(int ny, int size, int* ny_local, int* displs);
 
+/* How a run of n_steps iterations of d2q9-bgk.c:315-394 is cut into launches of the K-step kernels: steps[i] = the
+ * steps launch (or macro-step) i makes.  K at a time; with `four_rows` (a whole periodic grid, or a partition that
+ * keeps four ghost rows) a count K does not divide is split into 4s and 3s where that avoids a 1- or 2-step launch at
+ * the end (K = 4: n = 4a + 3, 4a + 6, 4a + 9; K = 3: n = 3a + 4, 3a + 8).  A function of its arguments only — every rank
+ * of a partitioned run plans the same sequence.  Returns the number of launches (at most `cap` entries are written),
+ * or -1 on a bad argument. */
+int lbm_plan_steps(int K, int four_rows, int n_steps, int* steps, int cap);
+
 /* ---- device state ---------------------------------------------------------------------------- */
 
 /* Replaces the allocation + initial-state part of initialise() (d2q9-bgk.c:865-911) for the rows

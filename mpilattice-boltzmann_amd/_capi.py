@@ -44,6 +44,7 @@ _SIGNATURES = {
     "lbm_read_params": (C.c_int, [C.c_char_p, _P(CParams)]),
     "lbm_read_obstacles": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_decompose": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "lbm_plan_steps": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), C.c_int]),
     "lbm_create": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_create_global": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_rank_layout": (C.c_int, [_P(CParams), C.c_int, C.c_int, C.c_uint, _P(CLayout)]),

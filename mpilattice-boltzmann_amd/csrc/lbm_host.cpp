@@ -104,6 +104,27 @@ int lbm_decompose(int ny, int size, int* ny_local, int* displs)
   return 0;
 }
 
+int lbm_plan_next(int K, int four_rows, int tail4, int left)
+{
+  int k = left < K ? left : K;
+  if (!four_rows || !tail4) return k;
+  if (K == 3 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
+  if (K == 4 && ((left % 4 == 3) || (left % 4 == 2 && left >= 6) || (left % 4 == 1 && left >= 9))) k = 3;
+  return k;
+}
+
+int lbm_plan_steps(int K, int four_rows, int n_steps, int* steps, int cap)
+{
+  if (K < 1 || K > 4 || n_steps < 0 || cap < 0 || (cap > 0 && !steps)) { lbm_internal::set_error("lbm_plan_steps: bad argument"); return -1; }
+  int n = 0;
+  for (int left = n_steps; left > 0; ++n) {
+    const int k = lbm_plan_next(K, four_rows, 1, left);
+    if (n < cap) steps[n] = k;
+    left -= k;
+  }
+  return n;
+}
+
 // d2q9-bgk.c:716-751 (without the MPI_Reduce): float accumulator, double sqrt.
 float lbm_av_velocity_host(const lbm_params* p, const float* cells, const int* obstacles, int rows)
 {

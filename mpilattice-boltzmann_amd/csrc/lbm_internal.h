@@ -7,3 +7,7 @@ namespace lbm_internal {
 // Sets the calling thread's lbm_last_error() message.
 void set_error(const std::string& msg);
 }  // namespace lbm_internal
+
+// Steps of the next launch of the K-step kernels when `left` steps remain (lbm_host.cpp; lbm_plan_steps is its public
+// form): shared by lbm_run, the split-phase macro-steps and the peer-to-peer loop, so that they cannot disagree.
+extern "C" int lbm_plan_next(int K, int four_rows, int tail4, int left);

@@ -438,12 +438,7 @@ hipError_t stream_wait(hipStream_t s)
 // rank of a partitioned run makes the same sequence of macro-steps.
 int next_multi_k(const lbm_ctx* c, int left)
 {
-  int k = std::min(c->multi_K, left);
-  const bool room = c->self_periodic || c->ghost >= 4;
-  if (!room || !c->multi_tail4) return k;
-  if (c->multi_K == 3 && ((left % 3 == 1 && left >= 4) || (left % 3 == 2 && left >= 8))) k = 4;
-  if (c->multi_K == 4 && ((left % 4 == 3) || (left % 4 == 2 && left >= 6) || (left % 4 == 1 && left >= 9))) k = 3;
-  return k;
+  return lbm_plan_next(c->multi_K, (c->self_periodic || c->ghost >= 4) ? 1 : 0, c->multi_tail4 ? 1 : 0, left);
 }
 
 constexpr int kGraphSteps = 64;   // even: the source/destination roles and the partial-sum parity return to their start

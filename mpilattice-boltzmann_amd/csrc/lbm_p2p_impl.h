@@ -567,7 +567,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       if (p2p_push(t, epoch, k0, cs, /*exposed=*/true)) return bail();
       sp.end = p2p_stamp(t, cs);
     }
-    sp_push.push_back(sp);
+    if (t->profile) sp_push.push_back(sp);
   }
   hipEvent_t e_steps0 = p2p_stamp(t, cs);
   int macro_steps = 0;
@@ -582,7 +582,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
         sp.begin = p2p_stamp(t, cs);
         launch_multi(c, k, more, c->multi_tiles_x, c->multi_tiles_x * rows.interior_rows, 0, 0, /*fold=*/c->n_prev > 0, cs);
         sp.end = p2p_stamp(t, cs);
-        sp_interior.push_back(sp);
+        if (t->profile) sp_interior.push_back(sp);
         c->n_prev = 0;
       }
       // MPI_Waitall (:364) happened on the device, at the end of the push kernel that precedes this launch
@@ -592,7 +592,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       launch_multi(c, k, more, 0, c->multi_tiles_x, (1 + rows.interior_rows) * c->multi_tiles_x, rows.top_edge_rows * c->multi_tiles_x,
                    /*fold=*/c->n_prev > 0, es);               // :365-366
       sp.end = p2p_stamp(t, es);
-      sp_edge.push_back(sp);
+      if (t->profile) sp_edge.push_back(sp);
       c->n_prev = 0;
       P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));
     } else {
@@ -600,7 +600,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       sp.begin = p2p_stamp(t, cs);
       launch_multi(c, k, more, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/c->n_prev > 0, cs);
       sp.end = p2p_stamp(t, cs);
-      sp_interior.push_back(sp);
+      if (t->profile) sp_interior.push_back(sp);
       c->n_prev = 0;
     }
     P2P_RUN_TRY(hipGetLastError());
@@ -619,7 +619,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       sp.begin = p2p_stamp(t, es);
       if (p2p_push(t, epoch + 1, next_multi_k(c, n_steps - done), es)) return bail();
       sp.end = p2p_stamp(t, es);
-      sp_push.push_back(sp);
+      if (t->profile) sp_push.push_back(sp);
     }
   }
   t->epoch = epoch - 1;

@@ -67,6 +67,17 @@ def decompose(ny: int, size: int) -> tuple[list[int], list[int]]:
     return list(nyl), list(dis)
 
 
+def plan_steps(K: int, n_steps: int, four_rows: bool = True) -> list[int]:
+    """`lbm_plan_steps`: the launches (macro-steps) a run of n_steps is cut into — K at a time, 4s and 3s at the end."""
+    lib = _capi.load_library()
+    n = lib.lbm_plan_steps(K, 1 if four_rows else 0, n_steps, None, 0)
+    if n < 0:
+        raise LbmError(lib.lbm_last_error().decode(errors="replace"))
+    out = (C.c_int * max(n, 1))()
+    lib.lbm_plan_steps(K, 1 if four_rows else 0, n_steps, out, n)
+    return [int(out[i]) for i in range(n)]
+
+
 def rank_layout(params: Params, nranks: int, rank: int, flags: int = 0) -> dict:
     """`lbm_rank_layout`: rows of `rank` by the reference's rule (`d2q9-bgk.c:834-862`) plus the stepping
     mode of the WHOLE run, derived from global quantities only — the same answer on every rank."""

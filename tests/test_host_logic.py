@@ -508,3 +508,28 @@ def test_saved_driver_style_line_recomputes_from_the_committed_counter_files():
     assert long_line["roofline"]["kernel"] == roof["kernel"]
     assert abs(long_line["roofline"]["avg_launch_ms"] * 1e6 / avg_ns - 1.0) < 0.10
     assert int(stats[full[dom]]["Calls"]) >= 20
+
+
+def test_step_plans_end_in_fours_and_threes(lbm):
+    """lbm_plan_steps — the one rule lbm_run, the split-phase macro-steps and the peer-to-peer loop cut a run by: K at a time,
+    and where four rows are there (whole grids; partitions with four ghost rows) a count K does not divide ends in 4s and 3s
+    instead of a 1- or 2-step launch (1050 / 1290 us per 3- / 4-step launch of the 8192 x 8192 deck against 870 / 1000 for a
+    1- / 2-step one).  Every plan adds up; short launches only where no mix of 3s and 4s exists (n = 1, 2, 5)."""
+    assert lbm.plan_steps(4, 20) == [4, 4, 4, 4, 4]
+    assert lbm.plan_steps(4, 21) == [3, 3, 3, 4, 4, 4]                # the odd launches come first
+    assert lbm.plan_steps(4, 22) == [3, 3, 4, 4, 4, 4]
+    assert lbm.plan_steps(4, 23) == [3, 4, 4, 4, 4, 4]
+    assert lbm.plan_steps(3, 20) == [4, 4, 3, 3, 3, 3]
+    assert lbm.plan_steps(3, 20, four_rows=False) == [3, 3, 3, 3, 3, 3, 2]
+    assert lbm.plan_steps(4, 6, four_rows=False) == [4, 2]
+    assert lbm.plan_steps(2, 7) == [2, 2, 2, 1] and lbm.plan_steps(4, 0) == []
+    for K in (3, 4):
+        for n in range(1, 200):
+            plan = lbm.plan_steps(K, n)
+            assert sum(plan) == n and all(1 <= k <= 4 for k in plan)
+            if n not in (1, 2, 5):
+                assert min(plan) >= 3, (K, n, plan)
+            plain = lbm.plan_steps(K, n, four_rows=False)
+            assert sum(plain) == n and all(k == K for k in plain[:-1]) and 1 <= plain[-1] <= K
+    with pytest.raises(lbm.LbmError):
+        lbm.plan_steps(5, 10)
