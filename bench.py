@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra timings: N=1: LBM_FLAG_FAST_AVVELS; partitioned runs: the RCCL loop and its per-step all-reduce mode")
     ap.add_argument("--no-secondary", action="store_true", help="partitioned runs: skip the shipped 1024x1024 deck (BASELINE.json config 4)")
+    ap.add_argument("--no-power", action="store_true", help="do not sample the card's socket power / shader clock (hwmon files) during the headline")
     ap.add_argument("--no-phases", action="store_true", help="skip the profiled extra repetition behind `phases` / the per-launch roofline timing")
     ap.add_argument("--secondary-steps", type=int, default=0, help="steps of the 1024x1024 deck (default: its own 20 000)")
     ap.add_argument("--no-verify", action="store_true", help="N>1: skip the bit-exact check against a single-GPU run of the same deck")
@@ -346,6 +347,98 @@ def load_roofline() -> dict | None:
         return None
 
 
+class PowerSampler:
+    """Socket power and shader clock of ONE card while a region runs, from the card's hwmon files (readable by an ordinary
+    user; no GPU call).  Why it is in the line: lbm_multi_kernel<4> runs AT the socket power limit (1380 of 1400 W, shader
+    clock ~2.2 of 2.4 GHz — scripts/power_trace.py), so neither the HBM nor the VALU fraction is the
+    binding limit: energy per cell-step is.  `pci` = "dddd:bb:dd.f" of the card (None: the card whose clock moved most)."""
+
+    FILES = {"power_uW": ("power1_input", "power1_average"), "cap_uW": ("power1_cap",), "sclk_Hz": ("freq1_input",)}
+
+    def __init__(self, pci: str | None, root: str = "/sys/class/drm", period_s: float = 0.002):
+        import glob
+        self.period_s, self.samples, self._stop, self._thread = period_s, {}, threading.Event(), None
+        self.cards = {}
+        seen = set()
+        for dev in sorted(glob.glob(os.path.join(root, "card*", "device"))):
+            real = os.path.realpath(dev)
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            if real in seen or not hw or (pci is not None and os.path.basename(real).lower() != pci.lower()):
+                continue
+            seen.add(real)
+            files = {k: next((os.path.join(hw[0], n) for n in names if os.path.exists(os.path.join(hw[0], n))), None)
+                     for k, names in self.FILES.items()}
+            if files["power_uW"] or files["sclk_Hz"]:
+                self.cards[os.path.basename(real)] = files
+        self.pci = pci
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _poll(self):
+        while not self._stop.is_set():
+            for name, files in self.cards.items():
+                self.samples.setdefault(name, []).append({k: self._read(p) for k, p in files.items()})
+            self._stop.wait(self.period_s)
+
+    def start(self):
+        if self.cards:
+            self._thread = threading.Thread(target=self._poll, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self) -> dict | None:
+        """Statistics of the samples taken while the shader clock was at least half its maximum over the region."""
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+
+        def swing(rows):
+            v = [r["sclk_Hz"] for r in rows if r.get("sclk_Hz") is not None]
+            return (max(v) - min(v)) if v else 0.0
+
+        if not self.samples:
+            return None
+        name = max(self.samples, key=lambda n: swing(self.samples[n]))
+        rows = self.samples[name]
+        clocks = [r["sclk_Hz"] for r in rows if r.get("sclk_Hz") is not None]
+        top = max(clocks) if clocks else 0.0
+        busy = [r for r in rows if (r.get("sclk_Hz") or 0.0) >= 0.5 * top] if top > 0 else rows
+
+        def med(key, scale):
+            v = sorted(r[key] * scale for r in busy if r.get(key) is not None)
+            return v[len(v) // 2] if v else None
+
+        def top_of(key, scale):
+            v = [r[key] * scale for r in busy if r.get(key) is not None]
+            return max(v) if v else None
+
+        out = {"card": name, "chosen_by": "pci address of the device" if self.pci else "largest clock swing among the visible cards",
+               "samples": len(rows), "samples_under_load": len(busy),
+               "socket_w_median": med("power_uW", 1e-6), "socket_w_max": top_of("power_uW", 1e-6), "cap_w": med("cap_uW", 1e-6),
+               "sclk_mhz_median": med("sclk_Hz", 1e-6), "sclk_mhz_max": top_of("sclk_Hz", 1e-6)}
+        if out["socket_w_median"] and out["cap_w"]:
+            out["frac_of_cap"] = out["socket_w_median"] / out["cap_w"]
+        out["note"] = ("hwmon power1_input / freq1_input of the card, polled every ~2 ms over the headline's settling and timed repetitions; "
+                       "statistics over the samples with the shader clock at >= half its maximum in the region")
+        return out
+
+
+def device_pci_address(index: int) -> str | None:
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    except Exception:                                     # noqa: BLE001 — telemetry only: never in the way of the measurement
+        return None
+
+
 def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, launch_profile, avg_launch_s: float, launches: int,
                     steps: int, pmc: dict | None, scale: float = 1.0, kernel_span_s: float | None = None) -> dict:
     """The `roofline` object of the line.  launch_profile: [(steps advanced, us)] per step-kernel launch of a profiled
@@ -359,7 +452,8 @@ def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, laun
                                          duration — exceeds 1 because lbm_multi_kernel<K> makes one HBM pass per K steps
       run_mix                            every instantiation the run launched (a 20-step run is 4 x K=3 + 2 x K=4): launches,
                                          live duration, profiled bytes; frac_hbm_physical_run = all bytes over all kernel time
-      limits.valu                        VALU busy share of a PROFILED pass (a constant of the commit, not of this run)"""
+      limits.valu                        VALU busy share of a PROFILED pass (a constant of the commit, not of this run)
+      limits.power                       added by main(): socket power / shader clock sampled live during the headline (PowerSampler)"""
     by_k: dict[int, list[float]] = {}
     time_scale = 1.0
     if launch_profile:
@@ -670,11 +764,14 @@ def main() -> int:
         return fail("no exchange mode completed: " + json.dumps(attempts))
 
     stage("headline: timed repetitions")
+    sampler = PowerSampler(device_pci_address(local_rank)).start() if rank == 0 and not args.no_power else None
     try:
         times, av = timed(sim, args.steps, args.reps)
         kernel_ms, launches = sim.partition.last_run_kernel_ms()
     except lbm.LbmError as e:
         return fail(f"run: {e}")
+    finally:
+        power = sampler.stop() if sampler is not None else None
     elapsed = float(np.median(times))
     assert av.shape == (args.steps,) and np.all(np.isfinite(av)) and np.all(av > 0)
     desc = sim.partition.describe()
@@ -751,6 +848,8 @@ def main() -> int:
             pmc = None
         roof = roofline_object(desc["kernel"], nx, ny, cells_per_launch, launch_profile, avg_launch_s, n_launch, args.steps, pmc, scale,
                                kernel_span_s=kernel_ms / 1e3)
+        if power is not None:
+            roof.setdefault("limits", {})["power"] = power
         exchange_txt = {"p2p": "direct peer-to-peer stores into the neighbours' ghost rows (xGMI), flags + one-wave wait kernels, "
                                "all-gather + local sum after the loop",
                         "rccl": "RCCL send/recv on a side stream, " + ("one all-reduce per macro-step" if what["step_allreduce"] else "one all-reduce after the loop"),
@@ -785,23 +884,34 @@ def main() -> int:
             out["exchange_attempts"] = attempts
         bank(out)                                          # from here on the watchdog has a line to print
 
-    # ---- N = 1: the same deck with LBM_FLAG_FAST_AVVELS (float sum|u| terms; default off) ---------------------------
+    # ---- N = 1: the same deck with the other two forms of the sum|u| terms (kernels/common.h finish_pair_lo) -----------
     if world == 1 and not args.ring and not args.no_variants:
-        stage("variant: fast av_vels")
-        variants = None
-        alt = lbm.Simulation(params, obstacles, device=local_rank, flags=flags | lbm._capi.FLAG_FAST_AVVELS)
-        if "fast av_vels" in alt.partition.describe()["kernel"]:
-            alt.run(args.warmup)
-            talt, av_alt = timed(alt, args.steps, args.reps, what="fast_av_vels")
-            med = float(np.median(talt))
-            variants = {"fast_av_vels": {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
-                                         "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt.astype(np.float64) - av) / av)),
-                                         "note": "LBM_FLAG_FAST_AVVELS: each cell's sum|u| term in float instead of double; populations "
-                                                 "identical bit for bit; NOT the headline (default off).  Measured in a second context of this process: where a "
-                                                 "context's grids land moves its step time by 3-5 % either way (DESIGN.md 4.2), so compare with a "
-                                                 "same-process A/B (scripts/ab_libs.py) rather than with `value`"}}
-        alt.close()
-        if variants is not None:
+        variants = {}
+        # av_vels of the three forms are compared from the SAME state: the deck's first `steps` steps in fresh contexts (the
+        # headline's context has advanced by its own number of settling repetitions)
+        base = lbm.Simulation(params, obstacles, device=local_rank, flags=flags)
+        av_first = base.run(args.steps).astype(np.float64)
+        base.close()
+        for vname, vflag, marker, vnote in (
+                ("fast_av_vels", lbm._capi.FLAG_FAST_AVVELS, "fast av_vels",
+                 "LBM_FLAG_FAST_AVVELS: each cell's sum|u| term in plain float"),
+                ("exact_av_vels", lbm._capi.FLAG_EXACT_AVVELS, "double-precision av_vels terms",
+                 "LBM_FLAG_EXACT_AVVELS: each term in double precision, correctly rounded (rounds 1-2's form), instead of the default's "
+                 "compensated float sums (relative error ~2^-44 per term)")):
+            stage(f"variant: {vname}")
+            alt = lbm.Simulation(params, obstacles, device=local_rank, flags=flags | vflag)
+            if marker in alt.partition.describe()["kernel"]:
+                av_alt = alt.run(args.steps).astype(np.float64)
+                talt, _ = timed(alt, args.steps, args.reps, what=vname)
+                med = float(np.median(talt))
+                variants[vname] = {"value": nx * ny * args.steps / med / 1e6, "unit": "MLUPS", "ms_per_step": med / args.steps * 1e3,
+                                   "av_vels_max_rel_diff_to_default": float(np.max(np.abs(av_alt - av_first) / av_first)),
+                                   "av_vels_values_that_differ": int(np.count_nonzero(av_alt != av_first)),
+                                   "note": vnote + "; populations identical bit for bit; NOT the headline.  Measured in another context of this "
+                                           "process: where a context's grids land moves its step time by 3-5 % either way (DESIGN.md 4.2), so "
+                                           "compare with a same-process A/B (scripts/ab_libs.py) rather than with `value`"}
+            alt.close()
+        if variants:
             out["variants"] = variants
             bank(out)
 

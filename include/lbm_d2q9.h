@@ -50,9 +50,12 @@ typedef struct lbm_ctx lbm_ctx;     /* opaque: device state of one partition */
                                        gain on MI355X, the small grids are bound by device-side launch latency) */
 #define LBM_FLAG_ONE_STEP     32u   /* row-partitioned run: keep the one-step split-phase calls (lbm_step_*) even when
                                        the partition is eligible for K-step mode (lbm_macro_*) */
-#define LBM_FLAG_FAST_AVVELS  64u   /* lbm_multi_kernel / lbm_tile_kernel form each cell's sum|u| term (d2q9-bgk.c:667) in float instead of
-                                       double: fewer instructions (0.6-9 % by box at 8192x8192, 3-4 % on the small decks), populations
-                                       unchanged bit for bit, av_vels equal to ~5e-8 instead of 1e-15 (default: off) */
+#define LBM_FLAG_FAST_AVVELS  64u   /* lbm_multi_kernel / lbm_tile_kernel form each cell's sum|u| term (d2q9-bgk.c:667) in float: populations
+                                       unchanged bit for bit, av_vels equal to ~1e-7 (an ulp of the float it is); 2-5 % faster */
+#define LBM_FLAG_EXACT_AVVELS 128u  /* lbm_multi_kernel forms the terms in double precision, each correctly rounded (as lbm_step_kernel and
+                                       lbm_tile_kernel always do) instead of as compensated float sums of relative error ~2^-44 (its
+                                       default: av_vels, a float, comes out the same; the launch runs at the socket power limit and the
+                                       double-precision instructions cost 1-2.5 % of clock) */
 #define LBM_FLAG_FORCE_HALO    8u   /* treat a whole-grid partition like any other rank: edge rows read the halo
                                        buffers (a 1-rank run that exchanges with itself, d2q9-bgk.c:245-247) */
 

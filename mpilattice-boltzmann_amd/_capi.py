@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 ABI_VERSION = 3
 NSPEEDS = 9
 
-FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP, FLAG_FAST_AVVELS = 0, 1, 2, 4, 8, 16, 32, 64
+FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP, FLAG_FAST_AVVELS, FLAG_EXACT_AVVELS = 0, 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class LbmError(RuntimeError):

@@ -323,13 +323,27 @@ __device__ __forceinline__ auto& at_byte(B* base, uint32_t byte_off)
 // ghost ring: they do not count, and the double-precision sqrt is a tenth of the cell's instructions).
 // tile_accel is block-uniform: false for the tiles whose frame does not meet row ny-2, which then skip
 // the accelerate_flow code instead of predicating it away in every pair.
-// FAST (LBM_FLAG_FAST_AVVELS, multi kernel only): the sum|u| term of a cell is formed in float — v_sqrt_f32
-// and one multiply instead of the ~20 double-precision instructions of sqrt((double)msq) * (double)rinv — and
-// widened for the double tree sum.  Populations are untouched; av_vels then agrees with the exact-term form to
-// ~1e-9 instead of 1e-15 (tests: 1e-6 against the oracle's exact sum, check.py's 1 % against the goldens).
-template <bool FAST = false>
-__device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
-                                              uint32_t skip, f2 (&out)[9])
+// TERMS: how the sum|u| term of a cell, sqrt((double)msq) * (double)rinv (:667), is formed.  Populations never depend on it.
+//   kTermsDouble (LBM_FLAG_EXACT_AVVELS; the tile and sweep kernels' default): in double precision, every term correctly
+//     rounded before the product: v_rsq_f64 + 9 double-precision instructions per CELL.
+//   kTermsCompensated (lbm_multi_kernel's default): without double-precision arithmetic.  The root as an unevaluated float
+//     sum s + c (s = msq * rsq(msq); c = the Newton correction of s from the residual msq - s*s, which a fused multiply-add
+//     delivers exactly), the product with rinv as p + lo (p = s * rinv, its rounding error by another fused multiply-add,
+//     plus c * rinv): relative error ~2^-44 per cell where the double form has 2^-53 — av_vels, a float, comes out bit for
+//     bit the same in every test here — in 7 packed float instructions and two v_rsq_f32 per PAIR.  Only p is widened per
+//     pair; the lo parts are summed per lane in float (a lane adds at most a few per launch) and widened once.  Why it
+//     matters: the launch runs AT the socket power limit (scripts/power_trace.py: 1380 of 1400 W, shader clock 2.2 of
+//     2.4 GHz); double-precision instructions it does not execute come back as clock.  A cell at rest (msq = 0) gives 0:
+//     the rsq argument is held at the smallest normal number.  msq = inf (a diverged run) gives NaN where the reference
+//     gives inf.
+//   kTermsFloat (LBM_FLAG_FAST_AVVELS): v_sqrt_f32 and one multiply; av_vels then agrees to ~1e-7 (an ulp of its float).
+constexpr int kTermsDouble = 0, kTermsFloat = 1, kTermsCompensated = 2;
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }     // v_pk_fma_f32
+
+template <int TERMS>
+__device__ __forceinline__ double finish_pair_lo(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
+                                                 uint32_t skip, f2 (&out)[9], float& lo_sum)
 {
   f2 o[9], msq, rinv;
   relax_core<f2>(t, omega, o, msq, rinv);                               // :546-666 on both cells at once (v_pk_*_f32)
@@ -358,10 +372,20 @@ __device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, 
   }
   double term = 0.0;
   if (skip != 3u) {
-    if constexpr (FAST) {
+    if constexpr (TERMS == kTermsFloat) {
       const f2 root = f2{__builtin_amdgcn_sqrtf(msq.x), __builtin_amdgcn_sqrtf(msq.y)};
       const f2 tf = root * rinv;
       term = static_cast<double>(((skip & 1u) ? 0.0f : tf.x) + ((skip & 2u) ? 0.0f : tf.y));
+    } else if constexpr (TERMS == kTermsCompensated) {
+      const f2 y = f2{__builtin_amdgcn_rsqf(__builtin_fmaxf(msq.x, 0x1p-126f)), __builtin_amdgcn_rsqf(__builtin_fmaxf(msq.y, 0x1p-126f))};
+      const f2 s = msq * y;                                  // ~sqrt(msq)
+      const f2 r = fma2(-s, s, msq);                         // msq - s*s
+      const f2 c = (r * y) * 0.5f;                           // sqrt(msq) ~ s + c
+      const f2 p = s * rinv;
+      const f2 e = fma2(s, rinv, -p);                        // s * rinv = p + e exactly
+      const f2 lo = fma2(c, rinv, e);
+      term = static_cast<double>((skip & 1u) ? 0.0f : p.x) + static_cast<double>((skip & 2u) ? 0.0f : p.y);
+      lo_sum += ((skip & 1u) ? 0.0f : lo.x) + ((skip & 2u) ? 0.0f : lo.y);
     } else {
       const double t0 = sqrt_of_float(msq.x) * static_cast<double>(rinv.x);   // :667
       const double t1 = sqrt_of_float(msq.y) * static_cast<double>(rinv.y);
@@ -369,6 +393,16 @@ __device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, 
     }
   }
   return term;
+}
+
+// The same with the pair's sum as one double (the tile and sweep kernels: TERMS = false / true = double / float).
+template <int TERMS = kTermsDouble>
+__device__ __forceinline__ double finish_pair(const f2 (&t)[9], uint32_t mbits, float omega, bool tile_accel, bool accel, float w1, float w2,
+                                              uint32_t skip, f2 (&out)[9])
+{
+  float lo = 0.0f;
+  const double hi = finish_pair_lo<TERMS>(t, mbits, omega, tile_accel, accel, w1, w2, skip, out, lo);
+  return TERMS == kTermsCompensated ? hi + static_cast<double>(lo) : hi;
 }
 
 

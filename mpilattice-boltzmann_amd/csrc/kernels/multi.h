@@ -108,7 +108,7 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
-template <int K, bool FAST, int TX>   // FAST: float sum|u| terms (LBM_FLAG_FAST_AVVELS), see finish_pair; TX: tile width
+template <int K, int TERMS, int TX>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; TX: tile width
 __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 160 * 1024) ? LBM_MWAVES : 4) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, TX>;
@@ -158,8 +158,9 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
   const int grid_cells = rows_storage * nx;
   constexpr int ksteps = K;
   double acc[K];
+  float acc_lo[K];             // kTermsCompensated: the low parts of a lane's terms, widened once at the end
 #pragma unroll
-  for (int i = 0; i < K; ++i) acc[i] = 0.0;
+  for (int i = 0; i < K; ++i) { acc[i] = 0.0; acc_lo[i] = 0.0f; }
 
   // does the LDS frame of this tile meet the global accelerate row ny-2 at all ?  (block-uniform)
   bool tile_accel;
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
                          (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
-      acc[0] += finish_pair<FAST>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out);
+      acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out, acc_lo[0]);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, fy * W, fx, out[k]);
@@ -302,11 +303,12 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
           p[6] = f2{lds[6 * kCells + cs - W], lds[6 * kCells + cs - W + WH + 1]};
           p[7] = f2{lds[7 * kCells + cs + W], lds[7 * kCells + cs + W + WH + 1]};
           const bool owned = lane_on && (fl & 4u);
-          const double term = finish_pair<FAST>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
-                                          owned ? (fl & 3u) : 3u, outs);
+          float term_lo = 0.0f;
+          const double term = finish_pair_lo<TERMS>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
+                                                    owned ? (fl & 3u) : 3u, outs, term_lo);
 #pragma unroll
           for (int m = 1; m < K; ++m)
-            if (m == j - 1) acc[m] += term;
+            if (m == j - 1) { acc[m] += term; acc_lo[m] += term_lo; }
           // an owned pair lies inside the grid: its cell index needs no periodic wrap
           slot = !lane_on ? -1 : last ? (owned ? tile_row_base + __mul24(fy - EY, nx) + x0 + fx - EX : -1) : fy * W - wr;   // in LDS: the row; fx is added below
         }
@@ -330,6 +332,10 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
   }
 
   // per-step sums over the owned cells of this tile
+  if constexpr (TERMS == kTermsCompensated) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] += static_cast<double>(acc_lo[i]);
+  }
   if constexpr (K == 1) {
     const double w = wave_sum(acc[0]);
     if ((tid & 63) == 0) red[tid >> 6] = w;

@@ -102,7 +102,8 @@ struct lbm_ctx {
   int accel_row = -1;
   int ghost = 0;             // storage rows below / above the owned rows (K-step kernels of a row-partitioned run)
   bool nt_stores = false;
-  bool fast_avvels = false;  // LBM_FLAG_FAST_AVVELS: float sum|u| terms in lbm_multi_kernel
+  bool fast_avvels = false;  // LBM_FLAG_FAST_AVVELS: float sum|u| terms in lbm_multi_kernel / lbm_tile_kernel
+  int multi_terms = kTermsCompensated;   // lbm_multi_kernel's form of the terms (kernels/common.h): LBM_FLAG_FAST_AVVELS / LBM_FLAG_EXACT_AVVELS
   size_t ncells = 0, ncells_storage = 0, ps = 0, grid_floats = 0;   // owned cells; cells incl. ghost rows; plane stride
   float* grid_alloc[2] = {nullptr, nullptr};
   float* grid[2] = {nullptr, nullptr};       // plane 0 row 0 (after the front guard)
@@ -246,26 +247,32 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
   }
 }
 
-template <int K, int TX>
-void launch_multi_kt(int blocks, hipStream_t s, const MultiArgs& a, bool fast)
+template <int K, int TX, int TERMS>
+void launch_multi_ktt(int blocks, hipStream_t s, const MultiArgs& a)
 {
   if constexpr (MultiGeom<K, TX>::lds_bytes > 65536) {       // experiment builds with taller tiles: frames above the default limit
     static bool raised = false;
     if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, true, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MultiGeom<K, TX>::lds_bytes));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, false, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MultiGeom<K, TX>::lds_bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, TERMS, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MultiGeom<K, TX>::lds_bytes));
       raised = true;
     }
   }
-  if (fast) lbm_multi_kernel<K, true, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
-  else lbm_multi_kernel<K, false, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
+  lbm_multi_kernel<K, TERMS, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
+}
+
+template <int K, int TX>
+void launch_multi_kt(int blocks, hipStream_t s, const MultiArgs& a, int terms)
+{
+  if (terms == kTermsFloat) launch_multi_ktt<K, TX, kTermsFloat>(blocks, s, a);
+  else if (terms == kTermsDouble) launch_multi_ktt<K, TX, kTermsDouble>(blocks, s, a);
+  else launch_multi_ktt<K, TX, kTermsCompensated>(blocks, s, a);
 }
 
 template <int K>
-void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, bool fast, int tile_x)
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int tile_x)
 {
-  if (tile_x == kMTXNarrow) launch_multi_kt<K, kMTXNarrow>(blocks, s, a, fast);
-  else launch_multi_kt<K, kMTX>(blocks, s, a, fast);
+  if (tile_x == kMTXNarrow) launch_multi_kt<K, kMTXNarrow>(blocks, s, a, terms);
+  else launch_multi_kt<K, kMTX>(blocks, s, a, terms);
 }
 
 // Tiles of a launch that makes `k` steps: the tile height depends on k (kernels/multi.h multi_ty).
@@ -296,10 +303,10 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
   switch (ksteps) {                                            // <= multi_K, or 4 in the tail of a K = 3 run (lbm_run)
-    case 1: launch_multi_k<1>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
-    case 2: launch_multi_k<2>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
-    case 3: launch_multi_k<3>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
-    default: launch_multi_k<4>(blocks, s, a, c->fast_avvels, c->multi_tx); break;
+    case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_tx); break;
+    case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_tx); break;
+    case 3: launch_multi_k<3>(blocks, s, a, c->multi_terms, c->multi_tx); break;
+    default: launch_multi_k<4>(blocks, s, a, c->multi_terms, c->multi_tx); break;
   }
 }
 
@@ -589,6 +596,11 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->y0 = y0; c->nyl = ny_local; c->device = device; c->flags = flags;
   c->self_periodic = self_periodic;
   c->fast_avvels = (flags & LBM_FLAG_FAST_AVVELS) != 0;
+  c->multi_terms = c->fast_avvels ? kTermsFloat : (flags & LBM_FLAG_EXACT_AVVELS) ? kTermsDouble : kTermsCompensated;
+  {
+    const int t = tune_env("LBM_TUNE_TERMS", -1);            // 0 double, 1 float, 2 compensated (A/B runs)
+    if (t >= 0 && t <= 2) c->multi_terms = t;
+  }
   c->accel_row = accel_row;
   c->accel_w1 = p->density * p->accel * 0.111111111111111111111111f;        // d2q9-bgk.c:445
   c->accel_w2 = p->density * p->accel * 0.0277777777777777777777778f;       // d2q9-bgk.c:446
@@ -1332,7 +1344,7 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
     if (c->sweep_R > 0 && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_sweep_kernel<%d, fast av_vels>" : "lbm_sweep_kernel<%d>", c->sweep_R);
-    else if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_multi_kernel<%d, fast av_vels>" : "lbm_multi_kernel<%d>", c->multi_K);
+    else if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->multi_terms == kTermsFloat ? "lbm_multi_kernel<%d, fast av_vels>" : c->multi_terms == kTermsDouble ? "lbm_multi_kernel<%d, double-precision av_vels terms>" : "lbm_multi_kernel<%d>", c->multi_K);
     else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_tile_kernel<%d, %d, fast av_vels>" : "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
     else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");

@@ -61,10 +61,11 @@ for n_spec, spec in enumerate(a.libs):    # "path.so", "path.so:FLAGS" (lbm_crea
 
 av = (C.c_float * a.steps)()
 res = {path: [] for path, _, _ in ctxs}
-digest = {}
+digest, first_av = {}, {}
 for path, lib, ctx in ctxs:
     lib.lbm_run(ctx, 12, av)
     digest[path] = bytes(av)[:48]
+    first_av[path] = np.array(av[:12], dtype=np.float32)
 for r in range(a.rounds):
     for path, lib, ctx in ctxs:
         if lib.lbm_run(ctx, a.steps, av):
@@ -77,5 +78,8 @@ for path, lib, ctx in ctxs:
     v = res[path]
     nd = 1 if min(v) >= 20 else 3
     same = "av==first" if digest[path] == ref else "av DIFFERS from first"
+    if digest[path] != ref:      # av_vels are floats: how many of the 12 differ, and by how much
+        a0, a1 = first_av[ctxs[0][0]].astype(np.float64), first_av[path].astype(np.float64)
+        same += f" ({int((a0 != a1).sum())}/12 values, max rel {np.max(np.abs(a1 - a0) / np.abs(a0)):.1e})"
     print(f"{path.split(':', 1)[0]:>2s} {os.path.basename(path.split(':', 1)[1]):50s} min {min(v):8.{nd}f}  med {statistics.median(v):8.{nd}f}  max {max(v):8.{nd}f} us/step   {same}", flush=True)
     lib.lbm_destroy(ctx)

@@ -17,7 +17,9 @@ B="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --reps 1"
 # the PMC passes run the DRIVER's step count: 20 steps = 2 x lbm_multi_kernel<4> + 4 x lbm_multi_kernel<3> launches, so that
 # both instantiations a driver-style line times are profiled (make_roofline.py keeps every kernel it finds)
 P="--steps 20 --warmup 5 --reps 2"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $B --steps 100 --warmup 10 > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err
+# the kernel trace runs the DEFAULT region (200 steps x 5 repetitions + warm-up: ~280 launches), so that the launches made while
+# the part ramps up from idle (up to 1.7 ms each, a dozen of them) weigh as little in its average as in bench.py's median
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${TAG}_fetch -o pmc -- python3 $B $P > /dev/null 2> $OUT/pmc_${TAG}_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${TAG}_write -o pmc -- python3 $B $P > /dev/null 2> $OUT/pmc_${TAG}_write.err

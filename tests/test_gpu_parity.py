@@ -1365,6 +1365,39 @@ def test_fast_av_vels_flag_against_the_oracle(lbm, oracle, digests, monkeypatch,
     assert np.max(np.abs(av_f.astype(np.float64) - av_e) / av_e) < 1e-6
 
 
+@pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 100), ("1024x1024_t200", 200), ("128x128", 50)])
+def test_three_forms_of_the_av_vels_terms(lbm, oracle, digests, monkeypatch, name, steps):
+    """lbm_multi_kernel's sum|u| terms (kernels/common.h finish_pair_lo): compensated float sums by default, double
+    precision with LBM_FLAG_EXACT_AVVELS, plain float with LBM_FLAG_FAST_AVVELS.  Populations never move by a bit; the
+    default's av_vels (floats) are the double-precision form's, value for value; as a 1-rank ring (tot_u in double) the two
+    agree to 1e-12 with each other and with the oracle's exact per-step sums."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    p, obst, free = load_case(lbm, digests, name)
+    sims = {"default": lbm.Simulation(p, obst), "exact": lbm.Simulation(p, obst, flags=lbm._capi.FLAG_EXACT_AVVELS),
+            "fast": lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FAST_AVVELS)}
+    names = {k: v.partition.describe()["kernel"] for k, v in sims.items()}
+    assert names["default"].endswith(">") and "av_vels" not in names["default"], names
+    assert "double-precision av_vels terms" in names["exact"] and "fast av_vels" in names["fast"], names
+    av = {k: v.run(steps) for k, v in sims.items()}
+    cells = {k: v.local_cells() for k, v in sims.items()}
+    for v in sims.values():
+        v.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    for k in sims:
+        assert np.array_equal(bits(cells[k]), bits(ref_cells)), k
+        assert np.max(np.abs(av[k].astype(np.float64) - ref_exact) / ref_exact) < AV_EXACT_RTOL, k
+    assert np.array_equal(av["default"], av["exact"])
+    tot = {}
+    for k, flags in (("default", 0), ("exact", lbm._capi.FLAG_EXACT_AVVELS)):
+        ring = lbm.Simulation(p, obst, flags=flags | lbm._capi.FLAG_FORCE_HALO, exchange="p2p", strict=True)
+        assert ring.loop == "p2p"
+        tot[k] = ring._p2p.run(steps) * np.float64(np.float32(1.0) / np.float32(free))
+        assert np.array_equal(bits(ring.local_cells()), bits(ref_cells))
+        ring.close()
+    assert np.max(np.abs(tot["default"] - tot["exact"]) / tot["exact"]) < 1e-12
+    assert np.max(np.abs(tot["default"] - ref_exact) / ref_exact) < 1e-12
+
+
 def test_launch_profile_and_ring_phases(lbm, digests, monkeypatch):
     """The profiling entry points behind bench.py's `roofline` and `phases` (the reference's MPI_Pcontrol("mainloop") region,
     d2q9-bgk.c:275-277,404-406): lbm_set_profile / lbm_launch_profile name every step-kernel launch of lbm_run with the steps it
