@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the kernel family on one GPU: every case runs the same deck through the
 library's own choice (lbm_multi_kernel / lbm_tile_kernel, random K / geometry / tile width, 1-rank rings over the
-peer-to-peer and the RCCL loop, with and without LBM_FLAG_FAST_AVVELS) and through the one-step
+peer-to-peer and the RCCL loop, with the three forms of the sum|u| terms) and through the one-step
 kernel (LBM_TUNE_MULTI_K=0, LBM_TUNE_TILE_MAX=0), and the final populations must agree bit for bit.
 No oracle involved (the one-step kernel is pinned to it by the test suite): thousands of cells x
 hundreds of shapes in a minute.
@@ -177,8 +177,8 @@ def fuzz(a) -> int:
                 flags = flags_fast
                 if kind == "ring":                                   # 1-rank ring over the peer-to-peer or the RCCL loop
                     flags, kw = lbm._capi.FLAG_FORCE_HALO, {"exchange": str(rng.choice(["p2p", "rccl"])), "strict": True}
-                if kind in ("multi", "tile", "ring") and rng.random() < 0.3:
-                    flags |= lbm._capi.FLAG_FAST_AVVELS                # float sum|u| terms: populations must not move
+                if kind in ("multi", "tile", "ring"):                # the other forms of the sum|u| terms: populations must not move
+                    flags |= int(rng.choice([0, 0, lbm._capi.FLAG_FAST_AVVELS, lbm._capi.FLAG_EXACT_AVVELS]))
             else:
                 os.environ.update({"LBM_TUNE_MULTI_K": "0", "LBM_TUNE_TILE_MAX": "0"})
             s = lbm.Simulation(p, obst, flags=flags, **kw)
