@@ -26,26 +26,38 @@ namespace {
 #define LBM_MTY 16
 #define LBM_MLANES 512
 #endif
-#ifndef LBM_MWAVES         // waves per SIMD the K <= 3 kernels are compiled for (register budget 512 / LBM_MWAVES)
+#ifndef LBM_MWAVES         // most waves per SIMD the kernels are compiled for (register budget 512 / LBM_MWAVES)
 #define LBM_MWAVES 6
 #endif
-#ifndef LBM_MTY4           // tile height of the 4-step instantiation
-#define LBM_MTY4 13
+#ifndef LBM_MTY4           // tile height and block size of the 4-step instantiation on 64-wide tiles
+#define LBM_MTY4 23
+#define LBM_MLANES4 768
 #endif
-constexpr int kMTX = 64, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMLanes = LBM_MLANES, kMaxMultiSteps = 4;
-// Tile height by steps per launch.  K <= 3: 64 x 16 tiles (K = 3: 72 x 20 frame, 51.8 KB, three blocks per CU).  K = 4 on
-// 64 x 16 tiles needs a 76 x 22 frame = 60 KB: two blocks per CU, and measured 353 - 363 us/step at 8192 x 8192 against 341
-// - 347 for K = 3.  On 64 x 13 tiles its frame is 76 x 19 = 52.0 KB — three blocks per CU again (3 x 52 962 B of 160 KB) —
-// and although a tile then recomputes 1.36 x its cells per step instead of 1.31 x, the launch moves 24.6 B per cell-step
-// instead of 26.9 with one kernel boundary per four steps: us/step for K = 3 / K = 4 on 64 x 12 / 64 x 13 / 64 x 11 tiles —
-// 8192 x 8192 346.6 / 322.8 / 324.0 / 336.4, 4096 x 4096 87.2 / 80.6 / 78.4 / 85.6, 2048 x 2048 24.0 / 23.3 / 21.6 / 23.8,
-// 1024 x 1024 8.16 / 7.50 / 7.07 / 7.55, 8192 x 1024 53.0 / 45.5 / 43.5 / 46.6, 512 x 512 3.11 / 3.44 / 3.45 / 3.28
-// (profiles/r03/ab_k3_k4.txt).  K = 4 is lbm_run's choice from 768 x 768 cells up and every K-step partition's.
-// (K = 3 on shorter tiles loses: 64 x 12 367, 64 x 10 at four blocks per CU 347 against 341.)
-constexpr int multi_ty(int k) { return k >= 4 ? kMTY4 : kMTY; }
+#ifndef LBM_MTY4N          // tile height of the 4-step instantiation on 32-wide tiles (partitions of less than a round of blocks)
+#define LBM_MTY4N 13
+#endif
+constexpr int kMTX = 64, kMTXNarrow = 32, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMTY4Narrow = LBM_MTY4N, kMLanes = LBM_MLANES, kMLanes4 = LBM_MLANES4,
+              kMaxMultiSteps = 4;
+constexpr int kMinMultiTY = kMTY < kMTY4 ? (kMTY < kMTY4Narrow ? kMTY : kMTY4Narrow) : (kMTY4 < kMTY4Narrow ? kMTY4 : kMTY4Narrow);
+// Tile height and block size by steps per launch (and tile width).
+//   K <= 3: 64 x 16 tiles, 512 lanes (K = 3: 72 x 20 frame, 51.8 KB, three blocks per CU).
+//   K = 4, rounds 1-2: on the same tiles a 76 x 22 frame = 60 KB, two blocks per CU: 353 - 363 us/step at 8192 x 8192 against 341 - 347
+//     for K = 3.
+//   K = 4, round 3 first: 64 x 13 tiles, 512 lanes: 76 x 19 frame = 52.0 KB, three blocks per CU again; a tile recomputes 1.36 x its
+//     cells per step instead of 1.31 x but the launch moves 21.5 B per cell-step instead of 26.9 — 8192 x 8192 346.6 (K = 3) -> 324.0,
+//     4096 x 4096 87.2 -> 78.4, 1024 x 1024 8.16 -> 7.07, 8192 x 1024 53.0 -> 43.5 (profiles/r03/ab_k3_k4.txt).
+//   K = 4, round 3 last: 64 x 23 tiles, 768 lanes: 76 x 29 frame = 79.3 KB, TWO blocks of twelve waves per CU (the same 24 waves): ring
+//     work 1.24 x, 37 -> 60 wave-passes for 1.77 x the cells.  With double-precision sum|u| terms this was a draw (310.8 against 311.9 -
+//     317.3, ab_k4_big_blocks_8192.txt); the launch runs at the socket power limit, and with the compensated float terms the form
+//     that does less work per cell wins everywhere — us/step 64 x 13 / 64 x 21 / 64 x 22 / 64 x 23 (768 lanes): 8192 x 8192 315.0 & 324.7 /
+//     304.6 / 307.7 / 303.9, 4096 x 4096 81.0 & 85.4 / 77.5 / 75.6 / 74.0, 8192 x 1024 43.6 & 44.1 / 40.5 / 40.2 / 39.9, 2048 x 2048
+//     22.3 & 22.8 / 22.3 / 21.5 / 21.6, 1024 x 1024 6.98 & 7.25 / 7.58 / 6.93 / 6.81 (ab_big_blocks_matrix.txt; 832- and 896-lane blocks
+//     and 1024-lane blocks at 64 VGPRs spill: 500 us/step).  32-wide tiles keep 13 rows and 512 lanes: they exist for launches of
+//     less than a round of blocks, where more, smaller blocks win.
+constexpr int multi_ty(int k, int tx = kMTX) { return k >= 4 ? (tx == kMTX ? kMTY4 : kMTY4Narrow) : kMTY; }
+constexpr int multi_lanes(int k, int tx = kMTX) { return (k >= 4 && tx == kMTX) ? kMLanes4 : kMLanes; }
 // Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:
 // twice the tiles, each with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
-constexpr int kMTXNarrow = 32;
 
 // Sub-step j of k (1-based) works on the owned tile grown by (k-j) rows and 2(k-j) columns on each
 // side: columns grow twice as fast so that every region starts on an even x and a lane can own an
@@ -59,11 +71,15 @@ constexpr int kMTXNarrow = 32;
 
 template <int K, int TX = kMTX>
 struct MultiGeom {
-  static constexpr int TY = multi_ty(K);                            // owned rows of a tile
+  static constexpr int TY = multi_ty(K, TX);                        // owned rows of a tile
+  static constexpr int LANES = multi_lanes(K, TX);                  // block size
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
   static constexpr int W = TX + 2 * EX, H = TY + 2 * EY;            // LDS frame
   static constexpr int cells = W * H;
-  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (kMLanes / 64) + (K >= 2 ? cells / 2 : 0);   // + a flag byte per x-pair
+  static constexpr size_t lds_bytes = sizeof(float) * 9 * cells + sizeof(double) * K * (LANES / 64) + (K >= 2 ? cells / 2 : 0);   // + a flag byte per x-pair
+  // waves per SIMD the kernel is compiled for: what its LDS frame lets a CU hold, LBM_MWAVES at most
+  static constexpr int blocks_per_cu = lds_bytes * 8 <= 160 * 1024 ? 8 : static_cast<int>(160 * 1024 / lds_bytes);
+  static constexpr int waves_per_simd = blocks_per_cu * (LANES / 64) / 4 < LBM_MWAVES ? (blocks_per_cu * (LANES / 64) / 4 < 1 ? 1 : blocks_per_cu * (LANES / 64) / 4) : LBM_MWAVES;
 };
 
 struct MultiArgs {
@@ -109,10 +125,10 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
 template <int K, int TERMS, int TX>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; TX: tile width
-__global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 160 * 1024) ? LBM_MWAVES : 4) lbm_multi_kernel(const MultiArgs a)
+__global__ void __launch_bounds__((MultiGeom<K, TX>::LANES), (MultiGeom<K, TX>::waves_per_simd)) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, TX>;
-  constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kWaves = kMLanes / 64, TY = G::TY;
+  constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kLanes = G::LANES, kWaves = kLanes / 64, TY = G::TY;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
   // per x-pair of the frame, written by sub-step 1 and read by the in-LDS sub-steps (which then need no
@@ -124,7 +140,7 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
     // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
     for (int v = 0; v < a.n_prev_vecs; ++v) {
       double s = 0.0;
-      for (int i = tid; i < a.n_prev; i += kMLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
+      for (int i = tid; i < a.n_prev; i += kLanes) s += a.prev_partials[static_cast<size_t>(v) * a.n_prev + i];
       s = wave_sum(s);
       __syncthreads();
       if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -186,7 +202,7 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
     const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + TY + EY + 1 <= rows_storage &&
                        sy0 + TY <= a.ghost + a.rows_owned;
 #pragma unroll 1
-    for (int i = tid; i < np; i += kMLanes) {
+    for (int i = tid; i < np; i += kLanes) {
       const int ry = i / wp, rp = i - ry * wp;
       const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
       int gx = x0 + fx - EX;
@@ -268,7 +284,7 @@ __global__ void __launch_bounds__(kMLanes, (MultiGeom<K, TX>::lds_bytes * 3 <= 1
       const int ey = ksteps - j, ex = 2 * ey;
       const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
       const int rows = TY + 2 * ey;
-      const int rpp = kMLanes / wp;                                      // whole rows per pass
+      const int rpp = kLanes / wp;                                       // whole rows per pass
       const bool last = j == ksteps;
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
       const int ry = tid / wp, rp = tid - ry * wp;

@@ -257,7 +257,7 @@ void launch_multi_ktt(int blocks, hipStream_t s, const MultiArgs& a)
       raised = true;
     }
   }
-  lbm_multi_kernel<K, TERMS, TX><<<dim3(blocks + 1), dim3(kMLanes), MultiGeom<K, TX>::lds_bytes, s>>>(a);
+  lbm_multi_kernel<K, TERMS, TX><<<dim3(blocks + 1), dim3(MultiGeom<K, TX>::LANES), MultiGeom<K, TX>::lds_bytes, s>>>(a);
 }
 
 template <int K, int TX>
@@ -276,7 +276,7 @@ void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, in
 }
 
 // Tiles of a launch that makes `k` steps: the tile height depends on k (kernels/multi.h multi_ty).
-int multi_tile_rows(const lbm_ctx* c, int k) { return (c->nyl + multi_ty(k) - 1) / multi_ty(k); }
+int multi_tile_rows(const lbm_ctx* c, int k) { return (c->nyl + multi_ty(k, c->multi_tx) - 1) / multi_ty(k, c->multi_tx); }
 int multi_tiles_for(const lbm_ctx* c, int k) { return c->multi_tiles_x * multi_tile_rows(c, k); }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
@@ -717,7 +717,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
-    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + std::min(kMTY, kMTY4) - 1) / std::min(kMTY, kMTY4)) + 1);
+    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
   } else if (!c->tile_kernel && self_periodic && fits_u32 && p->nx < (1 << 23) &&      // (24-bit row multiplies in lbm_multi_kernel)
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
@@ -733,7 +733,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tx = pick_tile_x(c->ncells);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
-    if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + std::min(kMTY, kMTY4) - 1) / std::min(kMTY, kMTY4)) + 1);
+    if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
     // streaming form of the 3-step launch (kernels/sweep.h): strips of 64 columns, segments of rows so that the launch is
     // about one round of two blocks per CU (8192 x 8192: 128 strips x 4 segments of 2048 rows = 512 blocks).
     // LBM_TUNE_SWEEP = R (rows per tick: 4 or 5); 0 = off (the default: measured 10-20 % slower than lbm_multi_kernel<3>)
@@ -1210,7 +1210,7 @@ int lbm_macro_next_steps(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run
 struct MacroRows { int interior_rows, top_edge_rows; };
 static MacroRows macro_rows(const lbm_ctx* c, int k)            // k = steps of the launch: the tile height follows it
 {
-  const int ty = multi_ty(k);
+  const int ty = multi_ty(k, c->multi_tx);
   const int nty = (c->nyl + ty - 1) / ty;
   const int last_rows = c->nyl - (nty - 1) * ty;
   int top = last_rows < c->ghost ? 2 : 1;                  // (ghost = the most steps a launch of this partition makes)
