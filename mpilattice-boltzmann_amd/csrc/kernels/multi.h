@@ -29,35 +29,38 @@ namespace {
 #ifndef LBM_MWAVES         // most waves per SIMD the kernels are compiled for (register budget 512 / LBM_MWAVES)
 #define LBM_MWAVES 6
 #endif
-#ifndef LBM_MTY4           // tile height and block size of the 4-step instantiation on 64-wide tiles
-#define LBM_MTY4 23
-#define LBM_MLANES4 768
+#ifndef LBM_MTY4           // tile height of the 4-step instantiation, standard and narrow geometry (512 lanes)
+#define LBM_MTY4 13
 #endif
-#ifndef LBM_MTY4N          // tile height of the 4-step instantiation on 32-wide tiles (partitions of less than a round of blocks)
-#define LBM_MTY4N 13
+#ifndef LBM_MTY4T          // tile height and block size of the 4-step instantiation, tall geometry
+#define LBM_MTY4T 23
+#define LBM_MLANES4T 768
 #endif
-constexpr int kMTX = 64, kMTXNarrow = 32, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMTY4Narrow = LBM_MTY4N, kMLanes = LBM_MLANES, kMLanes4 = LBM_MLANES4,
+constexpr int kMTX = 64, kMTXNarrow = 32, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMTY4Tall = LBM_MTY4T, kMLanes = LBM_MLANES, kMLanes4Tall = LBM_MLANES4T,
               kMaxMultiSteps = 4;
-constexpr int kMinMultiTY = kMTY < kMTY4 ? (kMTY < kMTY4Narrow ? kMTY : kMTY4Narrow) : (kMTY4 < kMTY4Narrow ? kMTY4 : kMTY4Narrow);
-// Tile height and block size by steps per launch (and tile width).
-//   K <= 3: 64 x 16 tiles, 512 lanes (K = 3: 72 x 20 frame, 51.8 KB, three blocks per CU).
-//   K = 4, rounds 1-2: on the same tiles a 76 x 22 frame = 60 KB, two blocks per CU: 353 - 363 us/step at 8192 x 8192 against 341 - 347
-//     for K = 3.
-//   K = 4, round 3 first: 64 x 13 tiles, 512 lanes: 76 x 19 frame = 52.0 KB, three blocks per CU again; a tile recomputes 1.36 x its
-//     cells per step instead of 1.31 x but the launch moves 21.5 B per cell-step instead of 26.9 — 8192 x 8192 346.6 (K = 3) -> 324.0,
-//     4096 x 4096 87.2 -> 78.4, 1024 x 1024 8.16 -> 7.07, 8192 x 1024 53.0 -> 43.5 (profiles/r03/ab_k3_k4.txt).
-//   K = 4, round 3 last: 64 x 23 tiles, 768 lanes: 76 x 29 frame = 79.3 KB, TWO blocks of twelve waves per CU (the same 24 waves): ring
-//     work 1.24 x, 37 -> 60 wave-passes for 1.77 x the cells.  With double-precision sum|u| terms this was a draw (310.8 against 311.9 -
-//     317.3, ab_k4_big_blocks_8192.txt); the launch runs at the socket power limit, and with the compensated float terms the form
-//     that does less work per cell wins everywhere — us/step 64 x 13 / 64 x 21 / 64 x 22 / 64 x 23 (768 lanes): 8192 x 8192 315.0 & 324.7 /
-//     304.6 / 307.7 / 303.9, 4096 x 4096 81.0 & 85.4 / 77.5 / 75.6 / 74.0, 8192 x 1024 43.6 & 44.1 / 40.5 / 40.2 / 39.9, 2048 x 2048
-//     22.3 & 22.8 / 22.3 / 21.5 / 21.6, 1024 x 1024 6.98 & 7.25 / 7.58 / 6.93 / 6.81 (ab_big_blocks_matrix.txt; 832- and 896-lane blocks
-//     and 1024-lane blocks at 64 VGPRs spill: 500 us/step).  32-wide tiles keep 13 rows and 512 lanes: they exist for launches of
-//     less than a round of blocks, where more, smaller blocks win.
-constexpr int multi_ty(int k, int tx = kMTX) { return k >= 4 ? (tx == kMTX ? kMTY4 : kMTY4Narrow) : kMTY; }
-constexpr int multi_lanes(int k, int tx = kMTX) { return (k >= 4 && tx == kMTX) ? kMLanes4 : kMLanes; }
-// Tile width TX: 64 (the bandwidth-bound grids) or 32 (partitions so small that a launch is one round of blocks:
-// twice the tiles, each with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
+constexpr int kMinMultiTY = kMTY < kMTY4 ? (kMTY < kMTY4Tall ? kMTY : kMTY4Tall) : (kMTY4 < kMTY4Tall ? kMTY4 : kMTY4Tall);
+// Geometry of a launch: tile width, and by steps per launch tile height and block size.
+//   kGeomStd     64-wide tiles.  K <= 3: 64 x 16, 512 lanes (K = 3: 72 x 20 frame, 51.8 KB, three blocks per CU).  K = 4 on the same tiles
+//                (rounds 1-2) needs a 76 x 22 frame = 60 KB, two blocks per CU: 353 - 363 us/step at 8192 x 8192 against 341 - 347 for
+//                K = 3.  On 64 x 13 tiles (round 3) its frame is 76 x 19 = 52.0 KB, three blocks per CU again: a tile recomputes 1.36 x
+//                its cells per step instead of 1.31 x but the launch moves 21.5 B per cell-step instead of 26.9 — 8192 x 8192 346.6
+//                (K = 3) -> 324.0, 4096 x 4096 87.2 -> 78.4, 1024 x 1024 8.16 -> 7.07, 8192 x 1024 53.0 -> 43.5 (profiles/r03/ab_k3_k4.txt).
+//   kGeomTall    K = 4 on 64 x 23 tiles with 768-lane blocks: 76 x 29 frame = 79.3 KB, TWO blocks of twelve waves per CU (the same 24
+//                waves): ring work 1.24 x, 60 wave-passes for 1.77 x the cells of 37.  With double-precision sum|u| terms this was a
+//                draw (310.8 against 311.9 - 317.3, ab_k4_big_blocks_8192.txt); the launch runs at the socket power limit, and with
+//                the compensated float terms the form that does less work per cell wins wherever a launch is rounds of blocks — us/step
+//                64 x 13 / 64 x 21 / 64 x 22 / 64 x 23 (768 lanes): 8192 x 8192 315.0 & 324.7 / 304.6 / 307.7 / 303.9, 4096 x 4096 81.0 & 85.4 /
+//                77.5 / 75.6 / 74.0, 8192 x 1024 43.6 & 44.1 / 40.5 / 40.2 / 39.9, 2048 x 2048 22.3 & 22.8 / 22.3 / 21.5 / 21.6, 1024 x 1024
+//                6.98 & 7.25 / 7.58 / 6.93 / 6.81 (ab_big_blocks_matrix.txt; 832-, 896- and 1024-lane blocks spill: 500 us/step) — and
+//                loses where it is one round or less (512 slots instead of 768): 768 x 768 4.91 against 4.56, 1024 x 768 6.20 / 5.57,
+//                1536 x 1536 13.1 / 13.1 (ab_k3_k4_threshold_768lanes.txt): the host picks it from 2^20 cells up.  K <= 3: as kGeomStd.
+//   kGeomNarrow  32-wide tiles, heights as kGeomStd: partitions so small that a launch is one round of blocks (twice the tiles, each
+//                with half the dependent work — a 1024 x 128-row partition keeps 256 CUs busy instead of 128).
+constexpr int kGeomStd = 0, kGeomNarrow = 1, kGeomTall = 2;
+constexpr int geom_tx(int g) { return g == kGeomNarrow ? kMTXNarrow : kMTX; }
+constexpr int multi_ty(int k, int g) { return k >= 4 ? (g == kGeomTall ? kMTY4Tall : kMTY4) : kMTY; }
+constexpr int multi_lanes(int k, int g) { return (k >= 4 && g == kGeomTall) ? kMLanes4Tall : kMLanes; }
+constexpr int geom_for(int k, int g) { return (g == kGeomTall && k < 4) ? kGeomStd : g; }      // the instantiation a launch of k steps uses
 
 // Sub-step j of k (1-based) works on the owned tile grown by (k-j) rows and 2(k-j) columns on each
 // side: columns grow twice as fast so that every region starts on an even x and a lane can own an
@@ -69,10 +72,11 @@ constexpr int multi_lanes(int k, int tx = kMTX) { return (k >= 4 && tx == kMTX) 
 #define LBM_MSTAMP(i) do { } while (0)
 #endif
 
-template <int K, int TX = kMTX>
+template <int K, int GEOM = kGeomStd>
 struct MultiGeom {
-  static constexpr int TY = multi_ty(K, TX);                        // owned rows of a tile
-  static constexpr int LANES = multi_lanes(K, TX);                  // block size
+  static constexpr int TX = geom_tx(GEOM);                          // owned columns of a tile
+  static constexpr int TY = multi_ty(K, GEOM);                      // owned rows of a tile
+  static constexpr int LANES = multi_lanes(K, GEOM);                // block size
   static constexpr int EY = K - 1, EX = 2 * (K - 1);                // growth of the first sub-step
   static constexpr int W = TX + 2 * EX, H = TY + 2 * EY;            // LDS frame
   static constexpr int cells = W * H;
@@ -124,11 +128,11 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
-template <int K, int TERMS, int TX>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; TX: tile width
-__global__ void __launch_bounds__((MultiGeom<K, TX>::LANES), (MultiGeom<K, TX>::waves_per_simd)) lbm_multi_kernel(const MultiArgs a)
+template <int K, int TERMS, int GEOM>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; GEOM: kGeomStd / Narrow / Tall
+__global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEOM>::waves_per_simd)) lbm_multi_kernel(const MultiArgs a)
 {
-  using G = MultiGeom<K, TX>;
-  constexpr int EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kLanes = G::LANES, kWaves = kLanes / 64, TY = G::TY;
+  using G = MultiGeom<K, GEOM>;
+  constexpr int TX = G::TX, EX = G::EX, EY = G::EY, W = G::W, WH = G::W / 2, kCells = G::cells, kLanes = G::LANES, kWaves = kLanes / 64, TY = G::TY;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
   // per x-pair of the frame, written by sub-step 1 and read by the in-LDS sub-steps (which then need no

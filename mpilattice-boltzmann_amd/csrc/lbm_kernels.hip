@@ -144,7 +144,8 @@ struct lbm_ctx {
   int n_prev_vecs = 1;       // ... and how many step vectors of that length the previous launch left (tile kernel: up to 8)
   int multi_K = 0;           // > 0: bandwidth-bound grid advanced K steps per launch by lbm_multi_kernel<K>
   int multi_tiles_x = 0, multi_tiles = 0;
-  int multi_tx = kMTX;       // tile width of lbm_multi_kernel: 64, or 32 for partitions of one round of blocks
+  int multi_geom = kGeomStd; // geometry of lbm_multi_kernel's launches (kernels/multi.h): standard, narrow (32-wide tiles), tall (K = 4 on 64 x 23)
+  int multi_tx = kMTX;       // its tile width: 64, or 32 for partitions of one round of blocks
   bool multi_tail4 = true;   // lbm_run at K = 3: 4-step launches instead of a 1- or 2-step tail (LBM_TUNE_MULTI_TAIL4)
   int sweep_R = 0;           // > 0: lbm_run's 3-step launches are lbm_sweep_kernel<R> (streaming temporal blocking, kernels/sweep.h)
   int sweep_nseg = 0, sweep_seg_rows = 0;
@@ -247,36 +248,38 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
   }
 }
 
-template <int K, int TX, int TERMS>
-void launch_multi_ktt(int blocks, hipStream_t s, const MultiArgs& a)
+template <int K, int GEOM, int TERMS>
+void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a)
 {
-  if constexpr (MultiGeom<K, TX>::lds_bytes > 65536) {       // experiment builds with taller tiles: frames above the default limit
+  using G = MultiGeom<K, GEOM>;
+  if constexpr (G::lds_bytes > 65536) {       // frames above the default limit of dynamic LDS (the tall geometry: 79 KB)
     static bool raised = false;
     if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, TERMS, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MultiGeom<K, TX>::lds_bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, TERMS, GEOM>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::lds_bytes));
       raised = true;
     }
   }
-  lbm_multi_kernel<K, TERMS, TX><<<dim3(blocks + 1), dim3(MultiGeom<K, TX>::LANES), MultiGeom<K, TX>::lds_bytes, s>>>(a);
+  lbm_multi_kernel<K, TERMS, GEOM><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
 }
 
-template <int K, int TX>
-void launch_multi_kt(int blocks, hipStream_t s, const MultiArgs& a, int terms)
+template <int K, int GEOM>
+void launch_multi_kg(int blocks, hipStream_t s, const MultiArgs& a, int terms)
 {
-  if (terms == kTermsFloat) launch_multi_ktt<K, TX, kTermsFloat>(blocks, s, a);
-  else if (terms == kTermsDouble) launch_multi_ktt<K, TX, kTermsDouble>(blocks, s, a);
-  else launch_multi_ktt<K, TX, kTermsCompensated>(blocks, s, a);
+  if (terms == kTermsFloat) launch_multi_kgt<K, GEOM, kTermsFloat>(blocks, s, a);
+  else if (terms == kTermsDouble) launch_multi_kgt<K, GEOM, kTermsDouble>(blocks, s, a);
+  else launch_multi_kgt<K, GEOM, kTermsCompensated>(blocks, s, a);
 }
 
 template <int K>
-void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int tile_x)
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int geom)
 {
-  if (tile_x == kMTXNarrow) launch_multi_kt<K, kMTXNarrow>(blocks, s, a, terms);
-  else launch_multi_kt<K, kMTX>(blocks, s, a, terms);
+  if (geom == kGeomNarrow) launch_multi_kg<K, kGeomNarrow>(blocks, s, a, terms);
+  else if (geom_for(K, geom) == kGeomTall) launch_multi_kg<K, geom_for(K, kGeomTall)>(blocks, s, a, terms);
+  else launch_multi_kg<K, kGeomStd>(blocks, s, a, terms);
 }
 
 // Tiles of a launch that makes `k` steps: the tile height depends on k (kernels/multi.h multi_ty).
-int multi_tile_rows(const lbm_ctx* c, int k) { return (c->nyl + multi_ty(k, c->multi_tx) - 1) / multi_ty(k, c->multi_tx); }
+int multi_tile_rows(const lbm_ctx* c, int k) { return (c->nyl + multi_ty(k, c->multi_geom) - 1) / multi_ty(k, c->multi_geom); }
 int multi_tiles_for(const lbm_ctx* c, int k) { return c->multi_tiles_x * multi_tile_rows(c, k); }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
@@ -303,10 +306,10 @@ void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
   switch (ksteps) {                                            // <= multi_K, or 4 in the tail of a K = 3 run (lbm_run)
-    case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_tx); break;
-    case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_tx); break;
-    case 3: launch_multi_k<3>(blocks, s, a, c->multi_terms, c->multi_tx); break;
-    default: launch_multi_k<4>(blocks, s, a, c->multi_terms, c->multi_tx); break;
+    case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_geom); break;
+    case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_geom); break;
+    case 3: launch_multi_k<3>(blocks, s, a, c->multi_terms, c->multi_geom); break;
+    default: launch_multi_k<4>(blocks, s, a, c->multi_terms, c->multi_geom); break;
   }
 }
 
@@ -520,16 +523,21 @@ static int macro_ghost_for(int k)
   return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_k), k), kMaxMultiSteps);
 }
 
-// Tile width of lbm_multi_kernel by partition size: 64 x 16 tiles for the bandwidth-bound grids; 32 x 16 where 64 x 16
+// Geometry of lbm_multi_kernel's launches by partition size.  Width: 64 x 16 tiles for the bandwidth-bound grids; 32 x 16 where 64 x 16
 // tiles would not even fill the chip once (256 CUs x 3 blocks), so that the launch is bound by one block's chain of
 // sub-steps: half the work per block, twice the blocks.  Measured us/step for 64 / 32 wide tiles (K = 3, one GPU):
 // 1024x128 3.22 / 2.53, 512x256 3.17 / 2.50, 512x512 3.42 / 3.44, 2048x256 4.94 / 5.05, 1024x1024 8.39 / 9.01.
-// LBM_TUNE_MULTI_TILE = 64 / 32 overrides.
-static int pick_tile_x(size_t ncells)
+// LBM_TUNE_MULTI_TILE = 64 / 32 overrides the width; LBM_TUNE_MULTI_GEOM = 0 / 1 / 2 the whole choice.
+// The tall geometry (K = 4 on 64 x 23 tiles, 768-lane blocks, two per CU) from 2^20 cells up: where a launch is several rounds of
+// blocks it is 4 - 10 % faster, at one round or less its 512 slots lose to 768 (kernels/multi.h).
+static int pick_geom(size_t ncells)
 {
   const int by_size = ncells <= static_cast<size_t>(tune_env("LBM_TUNE_NARROW_TILE_MAX", 1 << 17)) ? kMTXNarrow : kMTX;
   const int t = tune_env("LBM_TUNE_MULTI_TILE", by_size);
-  return t == kMTXNarrow ? kMTXNarrow : kMTX;
+  int g = t == kMTXNarrow ? kGeomNarrow : ncells >= static_cast<size_t>(tune_env("LBM_TUNE_TALL_TILE_MIN", 1 << 20)) ? kGeomTall : kGeomStd;
+  const int forced = tune_env("LBM_TUNE_MULTI_GEOM", -1);
+  if (forced >= kGeomStd && forced <= kGeomTall) g = forced;
+  return g;
 }
 
 // Obstacle bitfield of the storage rows: bit i of the linear storage cell index, row r of the storage taken
@@ -714,7 +722,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
-    c->multi_tx = pick_tile_x(c->ncells);
+    c->multi_geom = pick_geom(c->ncells);
+    c->multi_tx = geom_tx(c->multi_geom);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
@@ -730,7 +739,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // 1536x1536 14.2 / 13.8, 1024x1024 8.16 / 7.07, 768x768 5.39 / 4.63, 1024x512 4.51 / 4.72, 512x1024 4.39 / 4.62, 640x640 4.01 / 4.13,
     // 512x512 3.11 / 3.45 -> K = 4 from 768 x 768 cells up (profiles/r03/ab_k3_k4.txt, ab_k3_k4_threshold.txt)
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= size_t(768) * 768 ? 4 : 3), 0), kMaxMultiSteps);
-    c->multi_tx = pick_tile_x(c->ncells);
+    c->multi_geom = pick_geom(c->ncells);
+    c->multi_tx = geom_tx(c->multi_geom);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
@@ -1210,7 +1220,7 @@ int lbm_macro_next_steps(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run
 struct MacroRows { int interior_rows, top_edge_rows; };
 static MacroRows macro_rows(const lbm_ctx* c, int k)            // k = steps of the launch: the tile height follows it
 {
-  const int ty = multi_ty(k, c->multi_tx);
+  const int ty = multi_ty(k, c->multi_geom);
   const int nty = (c->nyl + ty - 1) / ty;
   const int last_rows = c->nyl - (nty - 1) * ty;
   int top = last_rows < c->ghost ? 2 : 1;                  // (ghost = the most steps a launch of this partition makes)
