@@ -530,11 +530,15 @@ static int macro_ghost_for(int k)
 // LBM_TUNE_MULTI_TILE = 64 / 32 overrides the width; LBM_TUNE_MULTI_GEOM = 0 / 1 / 2 the whole choice.
 // The tall geometry (K = 4 on 64 x 23 tiles, 768-lane blocks, two per CU) from 2^20 cells up: where a launch is several rounds of
 // blocks it is 4 - 10 % faster, at one round or less its 512 slots lose to 768 (kernels/multi.h).
-static int pick_geom(size_t ncells)
+// Row partitions (interior + edge launch per macro-step) keep the standard geometry: with two 79 KB frames per CU the edge launch
+// waits longer for a slot beside the interior launch and the macro-step's chain edge -> push -> edge stops hiding — 1-rank rings,
+// standard / tall, us/step: 8192 x 1024 46.7 / 56.9, 8192 x 2048 87.3 / 91.8, 8192 x 4096 159.4 / 162.5, while the same rows as ONE
+// periodic launch gain 3 - 5 % (41.8 / 40.7, 80.6 / 77.6, 152.6 / 145.6; profiles/r03/ab_ring_geom.txt).
+static int pick_geom(size_t ncells, bool partition)
 {
   const int by_size = ncells <= static_cast<size_t>(tune_env("LBM_TUNE_NARROW_TILE_MAX", 1 << 17)) ? kMTXNarrow : kMTX;
   const int t = tune_env("LBM_TUNE_MULTI_TILE", by_size);
-  int g = t == kMTXNarrow ? kGeomNarrow : ncells >= static_cast<size_t>(tune_env("LBM_TUNE_TALL_TILE_MIN", 1 << 20)) ? kGeomTall : kGeomStd;
+  int g = t == kMTXNarrow ? kGeomNarrow : (!partition && ncells >= static_cast<size_t>(tune_env("LBM_TUNE_TALL_TILE_MIN", 1 << 20))) ? kGeomTall : kGeomStd;
   const int forced = tune_env("LBM_TUNE_MULTI_GEOM", -1);
   if (forced >= kGeomStd && forced <= kGeomTall) g = forced;
   return g;
@@ -722,7 +726,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
-    c->multi_geom = pick_geom(c->ncells);
+    c->multi_geom = pick_geom(c->ncells, true);
     c->multi_tx = geom_tx(c->multi_geom);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
@@ -739,7 +743,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // 1536x1536 14.2 / 13.8, 1024x1024 8.16 / 7.07, 768x768 5.39 / 4.63, 1024x512 4.51 / 4.72, 512x1024 4.39 / 4.62, 640x640 4.01 / 4.13,
     // 512x512 3.11 / 3.45 -> K = 4 from 768 x 768 cells up (profiles/r03/ab_k3_k4.txt, ab_k3_k4_threshold.txt)
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= size_t(768) * 768 ? 4 : 3), 0), kMaxMultiSteps);
-    c->multi_geom = pick_geom(c->ncells);
+    c->multi_geom = pick_geom(c->ncells, false);
     c->multi_tx = geom_tx(c->multi_geom);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
