@@ -530,15 +530,16 @@ static int macro_ghost_for(int k)
 // LBM_TUNE_MULTI_TILE = 64 / 32 overrides the width; LBM_TUNE_MULTI_GEOM = 0 / 1 / 2 the whole choice.
 // The tall geometry (K = 4 on 64 x 23 tiles, 768-lane blocks, two per CU) from 2^20 cells up: where a launch is several rounds of
 // blocks it is 4 - 10 % faster, at one round or less its 512 slots lose to 768 (kernels/multi.h).
-// Row partitions (interior + edge launch per macro-step) keep the standard geometry: with two 79 KB frames per CU the edge launch
-// waits longer for a slot beside the interior launch and the macro-step's chain edge -> push -> edge stops hiding — 1-rank rings,
-// standard / tall, us/step: 8192 x 1024 46.7 / 56.9, 8192 x 2048 87.3 / 91.8, 8192 x 4096 159.4 / 162.5, while the same rows as ONE
-// periodic launch gain 3 - 5 % (41.8 / 40.7, 80.6 / 77.6, 152.6 / 145.6; profiles/r03/ab_ring_geom.txt).
+// Row partitions (interior + edge launch per macro-step) follow the same rule.  Measured one ring per PROCESS, as ranks run (two rings in
+// one process can share a hardware queue, which made the tall geometry look 20 % worse in a same-process A/B): standard / tall, us/step
+// at 200 and 20 steps per run: 8192 x 1024 rows 46.5 / 45.5 and 48.2 / 48.1, 8192 x 2048 rows 86.9 / 82.4 and 88.9 / 84.2
+// (profiles/r03/ab_fused_schedule.txt).
 static int pick_geom(size_t ncells, bool partition)
 {
   const int by_size = ncells <= static_cast<size_t>(tune_env("LBM_TUNE_NARROW_TILE_MAX", 1 << 17)) ? kMTXNarrow : kMTX;
   const int t = tune_env("LBM_TUNE_MULTI_TILE", by_size);
-  int g = t == kMTXNarrow ? kGeomNarrow : (!partition && ncells >= static_cast<size_t>(tune_env("LBM_TUNE_TALL_TILE_MIN", 1 << 20))) ? kGeomTall : kGeomStd;
+  (void)partition;
+  int g = t == kMTXNarrow ? kGeomNarrow : ncells >= static_cast<size_t>(tune_env("LBM_TUNE_TALL_TILE_MIN", 1 << 20)) ? kGeomTall : kGeomStd;
   const int forced = tune_env("LBM_TUNE_MULTI_GEOM", -1);
   if (forced >= kGeomStd && forced <= kGeomTall) g = forced;
   return g;
