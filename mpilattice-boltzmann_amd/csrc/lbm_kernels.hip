@@ -86,7 +86,13 @@ size_t plane_stride_floats(size_t ncells)
 {
   size_t s = round_up(ncells + 64, 64);
   if ((s / 64) % 2 == 0) s += 64;
-  if (ncells >= (1u << 20)) s += 64 * static_cast<size_t>(tune_env("LBM_TUNE_SKEW", 34));   // default ~8.5 KiB skew between planes for large grids
+  // Skew between planes for large grids (planes of 8192 x 8192 floats are 2^28 bytes: nine streams on the same channels without one).
+  // 24 x 256 B = 6 KiB.  Rounds 1-2 used 34 (tuned on the K = 3 launch, 64 x 16 tiles); scanned again on the K = 4 launch on 64 x 23 tiles,
+  // 8192 x 8192, us/step for skews 0 / 8 / 16 / 24 / 33 / 34 / 40 / 48 / 68: K = 4 286.7 / 284.6 / 285.8 / 284.7 / 314.3 / 307.8 & 295.3 / 289.0 /
+  // 285.1 / 286.6; K = 3 (the tails) 384.6 & 329.5 / 341.1 / 324.0 / 317.9 / 339.8 / 339.7 & 348.5 / 323.5 / 335.4 / 333.7 — 33 and 34 are the
+  // two bad values for the tall tiles, 24 is best for both; other sizes (4096 x 4096 ... 16384 x 4096, partitions) do not care
+  // (profiles/r03/ab_skew_scan.txt, ab_skew_sizes.txt).
+  if (ncells >= (1u << 20)) s += 64 * static_cast<size_t>(tune_env("LBM_TUNE_SKEW", 24));
   return s;
 }
 
