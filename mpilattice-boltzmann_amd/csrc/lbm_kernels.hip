@@ -540,11 +540,10 @@ static int macro_ghost_for(int k)
 // one process can share a hardware queue, which made the tall geometry look 20 % worse in a same-process A/B): standard / tall, us/step
 // at 200 and 20 steps per run: 8192 x 1024 rows 46.5 / 45.5 and 48.2 / 48.1, 8192 x 2048 rows 86.9 / 82.4 and 88.9 / 84.2
 // (profiles/r03/ab_fused_schedule.txt).
-static int pick_geom(size_t ncells, bool partition)
+static int pick_geom(size_t ncells)
 {
   const int by_size = ncells <= static_cast<size_t>(tune_env("LBM_TUNE_NARROW_TILE_MAX", 1 << 17)) ? kMTXNarrow : kMTX;
   const int t = tune_env("LBM_TUNE_MULTI_TILE", by_size);
-  (void)partition;
   int g = t == kMTXNarrow ? kGeomNarrow : ncells >= static_cast<size_t>(tune_env("LBM_TUNE_TALL_TILE_MIN", 1 << 20)) ? kGeomTall : kGeomStd;
   const int forced = tune_env("LBM_TUNE_MULTI_GEOM", -1);
   if (forced >= kGeomStd && forced <= kGeomTall) g = forced;
@@ -733,7 +732,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
-    c->multi_geom = pick_geom(c->ncells, true);
+    c->multi_geom = pick_geom(c->ncells);
     c->multi_tx = geom_tx(c->multi_geom);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
@@ -750,7 +749,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     // 1536x1536 14.2 / 13.8, 1024x1024 8.16 / 7.07, 768x768 5.39 / 4.63, 1024x512 4.51 / 4.72, 512x1024 4.39 / 4.62, 640x640 4.01 / 4.13,
     // 512x512 3.11 / 3.45 -> K = 4 from 768 x 768 cells up (profiles/r03/ab_k3_k4.txt, ab_k3_k4_threshold.txt)
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= size_t(768) * 768 ? 4 : 3), 0), kMaxMultiSteps);
-    c->multi_geom = pick_geom(c->ncells, false);
+    c->multi_geom = pick_geom(c->ncells);
     c->multi_tx = geom_tx(c->multi_geom);
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
