@@ -460,8 +460,10 @@ def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, laun
         # The events around every launch of the profiled repetition stretch it by a per cent or two.  The TIMED repetitions
         # carry only two events (first launch .. last launch, `kernel_span_s`): the profiled durations are scaled so that they
         # add up to that span — the profiled repetition supplies the SPLIT between instantiations, the timed region the time.
+        # (On the 64 x 23 / 768-lane launch the bracketed repetition of a 20-step region runs 20 - 25 % longer than a timed one: an event
+        # between two launches keeps the second from being set up behind the first.  The factor is reported: `launch_time_scale`.)
         total_us = sum(float(us) for _, us in launch_profile)
-        if kernel_span_s and total_us > 0 and 0.8 < kernel_span_s * 1e6 / total_us < 1.2:
+        if kernel_span_s and total_us > 0 and 0.5 < kernel_span_s * 1e6 / total_us < 1.5:
             time_scale = kernel_span_s * 1e6 / total_us
         for k, us in launch_profile:
             by_k.setdefault(int(k), []).append(float(us) * time_scale)
