@@ -609,6 +609,28 @@ def test_run_lengths_that_four_does_not_divide(lbm, oracle, digests, monkeypatch
     assert av.shape == (2 * steps,) and np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
 
 
+@pytest.mark.parametrize("geom,nx,ny,steps", [(None, 1346, 811, 11), (None, 1024, 1030, 9), ("2", 322, 140, 14), ("2", 128, 57, 10), ("0", 1154, 930, 7),
+                                              ("1", 1346, 811, 6)])
+def test_multi_kernel_geometries_on_ragged_grids(lbm, oracle, monkeypatch, geom, nx, ny, steps):
+    """The three launch geometries of lbm_multi_kernel<4> (kernels/multi.h: standard 64 x 13 / 512 lanes, narrow 32 x 13, tall 64 x 23 /
+    768 lanes — the library's choice from 2^20 cells up) on grids that no tile size divides: last tile column and row stick out of
+    the grid, step counts that 4 does not divide mix in the K = 3 launch (64 x 16), the run is cut in two.  Against the oracle."""
+    monkeypatch.setenv("LBM_TUNE_TILE_MAX", "0")
+    monkeypatch.setenv("LBM_TUNE_MULTI_K", "4")
+    if geom is not None:
+        monkeypatch.setenv("LBM_TUNE_MULTI_GEOM", geom)
+    p = lbm.Params(nx, ny, steps, 10, 0.1, 0.005, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.02, nx * 7 + ny, True)
+    s = lbm.Simulation(p, obst)
+    assert s.partition.describe()["kernel"] == "lbm_multi_kernel<4>"
+    av = np.concatenate([s.run(steps - 4), s.run(4)])
+    cells = s.local_cells()
+    s.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / np.maximum(ref_exact, 1e-30)) < AV_EXACT_RTOL
+
+
 @pytest.mark.parametrize("mode", ["2", "1", "0"])
 @pytest.mark.parametrize("R", [5, 4])
 @pytest.mark.parametrize("nx,ny,steps,blocks", [(128, 64, 7, 4), (64, 96, 9, 3), (256, 200, 12, 8), (192, 77, 10, 6), (512, 512, 31, 512),
