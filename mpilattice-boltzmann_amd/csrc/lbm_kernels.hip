@@ -258,14 +258,24 @@ template <int K, int GEOM, int TERMS>
 void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a)
 {
   using G = MultiGeom<K, GEOM>;
-  if constexpr (G::lds_bytes > 65536) {       // frames above the default limit of dynamic LDS (the tall geometry: 79 KB)
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbm_multi_kernel<K, TERMS, GEOM>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::lds_bytes));
-      raised = true;
+  lbm_multi_kernel<K, TERMS, GEOM><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+}
+
+// Frames above the default limit of dynamic LDS (the tall geometry: 79 KB) need the limit raised — per DEVICE (a function attribute
+// belongs to the device's copy of the code object): called from lbm_create on the context's device, not from the first launch of a process.
+template <int K, int GEOM>
+hipError_t raise_multi_lds_limit()
+{
+  using G = MultiGeom<K, GEOM>;
+  if constexpr (G::lds_bytes > 65536) {
+    const void* fns[3] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM>)};
+    for (const void* f : fns) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::lds_bytes));
+      if (e != hipSuccess) return e;
     }
   }
-  lbm_multi_kernel<K, TERMS, GEOM><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  return hipSuccess;
 }
 
 template <int K, int GEOM>
@@ -274,6 +284,23 @@ void launch_multi_kg(int blocks, hipStream_t s, const MultiArgs& a, int terms)
   if (terms == kTermsFloat) launch_multi_kgt<K, GEOM, kTermsFloat>(blocks, s, a);
   else if (terms == kTermsDouble) launch_multi_kgt<K, GEOM, kTermsDouble>(blocks, s, a);
   else launch_multi_kgt<K, GEOM, kTermsCompensated>(blocks, s, a);
+}
+
+template <int GEOM>
+hipError_t raise_multi_lds_limits()
+{
+  hipError_t e = raise_multi_lds_limit<1, GEOM>();
+  if (e == hipSuccess) e = raise_multi_lds_limit<2, GEOM>();
+  if (e == hipSuccess) e = raise_multi_lds_limit<3, GEOM>();
+  if (e == hipSuccess) e = raise_multi_lds_limit<4, GEOM>();
+  return e;
+}
+hipError_t raise_multi_lds_limits_for(int geom)          // every instantiation a context of this geometry may launch (K = 3 tails of the tall one: standard)
+{
+  if (geom == kGeomNarrow) return raise_multi_lds_limits<kGeomNarrow>();
+  hipError_t e = raise_multi_lds_limits<kGeomStd>();
+  if (e == hipSuccess && geom == kGeomTall) e = raise_multi_lds_limit<4, kGeomTall>();
+  return e;
 }
 
 template <int K>
@@ -734,6 +761,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->tile_kernel = false;
     c->multi_geom = pick_geom(c->ncells);
     c->multi_tx = geom_tx(c->multi_geom);
+    HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
@@ -751,6 +779,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_K = std::min(std::max(tune_env("LBM_TUNE_MULTI_K", c->ncells >= size_t(768) * 768 ? 4 : 3), 0), kMaxMultiSteps);
     c->multi_geom = pick_geom(c->ncells);
     c->multi_tx = geom_tx(c->multi_geom);
+    HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);

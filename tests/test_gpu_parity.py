@@ -1098,7 +1098,7 @@ def test_p2p_ranks_in_separate_processes_share_the_gpu(lbm, ranks):
     import json
     import sys
     from conftest import ROOT
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBM_P2P_TIMEOUT_MS="20000")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBM_P2P_TIMEOUT_MS="60000", GLOO_SOCKET_IFNAME="lo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), json.dumps(P2P_CASES[ranks])]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
