@@ -1102,6 +1102,12 @@ def test_p2p_ranks_in_separate_processes_share_the_gpu(lbm, ranks):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "p2p_worker.py"), json.dumps(P2P_CASES[ranks])]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    if r.returncode != 0 and "FAILED" not in r.stdout:
+        # the rank processes did not get as far as a verdict (rendezvous, a rank starved of the shared GPU past the time-out ...): once more,
+        # on a new port.  A case that ran and DIFFERS is never retried.
+        print("first attempt:", r.stdout[-1500:], r.stderr[-3000:])
+        cmd[cmd.index("--master-port") + 1] = str(free_port())
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
     assert r.returncode == 0 and len(lines) == len(P2P_CASES[ranks]) and all(" ok " in l for l in lines), (r.stdout[-2000:], r.stderr[-3000:])
 
