@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--step-allreduce", action="store_true",
                     help="RCCL loop: one all-reduce per (macro-)step instead of one after the loop (north_star wording; measured mode)")
     ap.add_argument("--no-variants", action="store_true",
-                    help="skip the extra timings: N=1: LBM_FLAG_FAST_AVVELS; partitioned runs: the RCCL loop and its per-step all-reduce mode")
+                    help="skip the extra timings: N=1: the other two forms of the sum|u| terms (LBM_FLAG_FAST_AVVELS, LBM_FLAG_EXACT_AVVELS); partitioned runs: the RCCL loop and its per-step all-reduce mode")
     ap.add_argument("--no-secondary", action="store_true", help="partitioned runs: skip the shipped 1024x1024 deck (BASELINE.json config 4)")
     ap.add_argument("--no-power", action="store_true", help="do not sample the card's socket power / shader clock (hwmon files) during the headline")
     ap.add_argument("--no-phases", action="store_true", help="skip the profiled extra repetition behind `phases` / the per-launch roofline timing")
