@@ -31,6 +31,7 @@ def main() -> int:
     torch.cuda.set_device(device)
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
+    print(f"RANK {rank} UP", flush=True)          # the group exists: whatever happens from here on is a verdict, never retried (conftest.py)
     bad = 0
     for i, c in enumerate(cases):
         exchange = c.get("exchange", "p2p")

@@ -568,3 +568,24 @@ def test_step_plans_end_in_fours_and_threes(lbm):
             assert sum(plain) == n and all(k == K for k in plain[:-1]) and 1 <= plain[-1] <= K
     with pytest.raises(lbm.LbmError):
         lbm.plan_steps(5, 10)
+
+
+def test_only_a_failed_rendezvous_is_ever_run_again():
+    """conftest.is_rendezvous_failure — the one condition under which a test may start its rank processes a second time: they never
+    formed their group.  A bounded wait of the peer-to-peer loop that ran out (the visible form of a hang), an LbmError of any kind,
+    an assert in the worker, a GPU fault, a rank killed by a signal, a parity FAILED line: each is a verdict and stays one."""
+    from conftest import is_rendezvous_failure as again
+    gloo = "RuntimeError: [../third_party/gloo/gloo/transport/tcp/pair.cc:144] Gloo connectFullMesh failed with Connection refused"
+    summary = "Root Cause (first observed failure):\n[0]:\n  rank      : 1 (local_rank: 1)\n  exitcode  : {code} (pid: 77)\n"
+    assert again(1, "", gloo + "\n" + summary.format(code=1))
+    assert again(1, "", "torch.distributed.DistNetworkError: The client socket has timed out after 600s\n")
+    assert again(1, "", "Other Failures:\n  exitcode  : -15 (pid: 76)\n" + gloo + "\n" + summary.format(code=1))    # the agent's SIGTERMs do not count
+    assert not again(0, "", gloo)                                                                    # it passed
+    assert not again(1, "RANK 0 UP\n", gloo)                                                         # the group had formed
+    assert not again(1, "", "mpilattice-boltzmann_amd._capi.LbmError: lbm_p2p_run: rank 1: a peer's data did not arrive in time [code 1]\n" + gloo)
+    assert not again(1, "", "lbm_p2p_run: rank 0: a neighbour's grids are out of step with this rank's\n" + gloo)
+    assert not again(1, "CASE 0 FAILED ranks=2\n", gloo)
+    assert not again(1, "", "AssertionError: {'loop': 'rccl'}\n" + gloo)
+    assert not again(1, "", "Memory access fault by GPU node-2\n" + gloo)
+    assert not again(1, "", gloo + "\n" + summary.format(code=-11))                                  # the first rank to fail died of a signal
+    assert not again(1, "", "something else went wrong\n" + summary.format(code=1))                  # no rendezvous text at all
