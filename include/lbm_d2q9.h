@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 3
+#define LBM_ABI_VERSION 4
 #define LBM_NSPEEDS 9               /* d2q9-bgk.c:62 */
 
 /* Run constants as read from the parameter file: t_param (d2q9-bgk.c:79-90) minus free_cells_inv,
@@ -82,6 +82,12 @@ int lbm_decompose(int ny, int size, int* ny_local, int* displs);
  * of a partitioned run plans the same sequence.  Returns the number of launches (at most `cap` entries are written),
  * or -1 on a bad argument. */
 int lbm_plan_steps(int K, int four_rows, int n_steps, int* steps, int cap);
+/* A row-partitioned run exchanges halo rows (d2q9-bgk.c:326-328,364) once per GROUP of launches: the launches lbm_plan_steps gives
+ * (with four_rows = ghost >= 4), taken for as long as their steps add up to at most `ghost` — the rows kept on each side of the owned
+ * rows (lbm_layout.ghost) — and at most `group_max` of them (lbm_layout.group).  steps[i] = the steps of launch i of the group that
+ * starts when `left` steps of the run remain; returns the number of launches (>= 1 when left > 0), -1 on a bad argument.  Again a
+ * function of its arguments only: every rank plans the same groups. */
+int lbm_plan_group(int K, int ghost, int group_max, int left, int* steps, int cap);
 
 /* ---- device state ---------------------------------------------------------------------------- */
 
@@ -117,8 +123,9 @@ int lbm_create_global(lbm_ctx** ctx, const lbm_params* p, int free_cells, const 
 typedef struct lbm_layout {
   int y0, ny_local;                 /* rows [y0, y0+ny_local) of the global grid belong to the rank */
   int macro_k;                      /* K of K-step mode for the whole run, or 0 */
-  int ghost;                        /* rows kept (and obstacle rows to supply) below and above the owned rows: macro_k, or 4 at
-                                       macro_k = 3 so that a step count 3 does not divide ends in 3s and 4s (LBM_TUNE_MACRO_GHOST) */
+  int ghost;                        /* rows kept (and obstacle rows to supply) below and above the owned rows: 2 * macro_k (8 at macro_k = 3):
+                                       the launches between two halo exchanges make at most that many steps together (LBM_TUNE_MACRO_GHOST) */
+  int group;                        /* most launches per halo exchange: ghost / macro_k (LBM_TUNE_MACRO_GROUP) */
 } lbm_layout;
 int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, lbm_layout* out);
 
@@ -185,24 +192,28 @@ int    lbm_step_prepare(lbm_ctx* ctx, int n_steps, void* stream);
 int    lbm_step_interior(lbm_ctx* ctx, void* stream);
 int    lbm_step_boundary(lbm_ctx* ctx, void* stream);
 int    lbm_step_finish(lbm_ctx* ctx, void* stream);
-/* ---- K-step stepping of a row-partitioned run (contexts from lbm_create_global) ------------------
+/* ---- K-step stepping of a row-partitioned run (contexts from lbm_create_rank / lbm_create_global) ----
  *
- * One macro-step = lbm_macro_next_steps() iterations of d2q9-bgk.c:315-378 with ONE halo exchange — K of them, fewer
- * at the end of a run, and where the partition keeps four ghost rows at K = 3 a step count that 3 does not divide is
- * split into 3s and 4s; the sequence depends on (K, ghost rows, steps left) only, so every rank makes the same one:
+ * One macro-step = ONE halo exchange followed by a group of lbm_macro_next_launches() launches that together make
+ * lbm_macro_next_steps() iterations of d2q9-bgk.c:315-378 — by default two launches of K = 4 steps on 8 ghost rows; fewer at
+ * the end of a run, where a step count K does not divide is split into 4s and 3s; lbm_plan_group gives the sequence, which
+ * depends on (K, ghost rows, launches per exchange, steps left) only, so every rank makes the same one:
  *     [caller: for each of the 9 planes, send lbm_macro_send_ptr(dir, plane) to the neighbour in
  *      direction dir and receive lbm_macro_recv_ptr(dir, plane) from it: lbm_macro_halo_floats()
  *      floats = `ghost` whole rows each; the pointers refer to the CURRENT grid and change every macro-step]
- *     lbm_macro_interior(ctx, stream)   tiles that need no ghost row, overlaps the exchange
+ *     lbm_macro_interior(ctx, stream)   first launch of the group, tiles that need no ghost row: overlaps the exchange
  *     [exchange complete]
- *     lbm_macro_edge(ctx, stream)       first and last tile row
- *     lbm_macro_finish(ctx, stream)     swap grids, advance the step counter by the macro-step's steps
+ *     lbm_macro_edge(ctx, stream)       first launch of the group, first and last tile rows
+ *     lbm_macro_finish(ctx, stream)     swap grids, advance the step counter; then the group's LATER launches, each over all tiles,
+ *                                       on `stream` — they read the ghost rows the first launch advanced, no exchanged row: `stream`
+ *                                       must be ordered behind both launches above when lbm_macro_next_launches() > 1
  * lbm_macro_prepare / lbm_step_collect / lbm_step_sums_device_ptr play the roles they have above.
  * lbm_macro_steps(): K, or 0 when the context is not in K-step mode (use lbm_step_* then).
  * lbm_macro_exchange_local(): the exchange between two contexts of one process (device copies):
  * src's rows travelling in direction dir become dst's ghost rows. */
 int    lbm_macro_steps(const lbm_ctx* ctx);
 int    lbm_macro_next_steps(const lbm_ctx* ctx);   /* steps of the macro-step about to be made (0: no run in progress) */
+int    lbm_macro_next_launches(const lbm_ctx* ctx);/* launches of that macro-step */
 size_t lbm_macro_halo_floats(const lbm_ctx* ctx);
 void*  lbm_macro_send_ptr(lbm_ctx* ctx, int dir, int plane);
 void*  lbm_macro_recv_ptr(lbm_ctx* ctx, int dir, int plane);

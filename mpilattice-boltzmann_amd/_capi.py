@@ -13,7 +13,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NSPEEDS = 9
 
 FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP, FLAG_FAST_AVVELS, FLAG_EXACT_AVVELS = 0, 1, 2, 4, 8, 16, 32, 64, 128
@@ -33,7 +33,7 @@ class CParams(C.Structure):
 class CLayout(C.Structure):
     """struct lbm_layout."""
 
-    _fields_ = [("y0", C.c_int), ("ny_local", C.c_int), ("macro_k", C.c_int), ("ghost", C.c_int)]
+    _fields_ = [("y0", C.c_int), ("ny_local", C.c_int), ("macro_k", C.c_int), ("ghost", C.c_int), ("group", C.c_int)]
 
 
 _P = C.POINTER
@@ -45,6 +45,7 @@ _SIGNATURES = {
     "lbm_read_obstacles": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_decompose": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_plan_steps": (C.c_int, [C.c_int, C.c_int, C.c_int, _P(C.c_int), C.c_int]),
+    "lbm_plan_group": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P(C.c_int), C.c_int]),
     "lbm_create": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_create_global": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_rank_layout": (C.c_int, [_P(CParams), C.c_int, C.c_int, C.c_uint, _P(CLayout)]),
@@ -66,6 +67,7 @@ _SIGNATURES = {
     "lbm_step_finish": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_steps": (C.c_int, [_ctx]),
     "lbm_macro_next_steps": (C.c_int, [_ctx]),
+    "lbm_macro_next_launches": (C.c_int, [_ctx]),
     "lbm_macro_halo_floats": (C.c_size_t, [_ctx]),
     "lbm_macro_send_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
     "lbm_macro_recv_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),

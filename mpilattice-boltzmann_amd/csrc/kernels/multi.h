@@ -37,7 +37,9 @@ namespace {
 #define LBM_MLANES4T 768
 #endif
 constexpr int kMTX = 64, kMTXNarrow = 32, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMTY4Tall = LBM_MTY4T, kMLanes = LBM_MLANES, kMLanes4Tall = LBM_MLANES4T,
-              kMaxMultiSteps = 4;
+              kMaxMultiSteps = 4,
+              kMaxGhost = 16,      // most ghost rows a K-step partition keeps per side: the steps of a group of launches between two halo exchanges
+              kMaxGroup = 8;       // most launches of such a group
 constexpr int kMinMultiTY = kMTY < kMTY4 ? (kMTY < kMTY4Tall ? kMTY : kMTY4Tall) : (kMTY4 < kMTY4Tall ? kMTY4 : kMTY4Tall);
 // Geometry of a launch: tile width, and by steps per launch tile height and block size.
 //   kGeomStd     64-wide tiles.  K <= 3: 64 x 16, 512 lanes (K = 3: 72 x 20 frame, 51.8 KB, three blocks per CU).  K = 4 on the same tiles
@@ -94,10 +96,16 @@ struct MultiArgs {
   const uint32_t* mask;        // bit per STORAGE cell (ghost rows included)
   size_t ps;
   int nx;
-  int rows_owned;              // owned rows
-  int ghost;                   // storage rows before the first owned row (0 when y_periodic)
+  // Rows, all in STORAGE coordinates (row 0 = the first ghost row, or the first grid row of a whole periodic grid).  A launch
+  // computes the rows [row_first, row_first + rows_compute): the owned rows, or — the first launches of a group that makes several
+  // launches per halo exchange (lbm_p2p_impl.h) — the owned rows and `ext` ghost rows on each side, which the later launches of the
+  // group then read instead of exchanged rows.  Only cells of the rows [count_first, count_end) — the rows the partition OWNS — enter the
+  // per-step sums (the neighbours count theirs).
+  int row_first, rows_compute;
+  int rows_storage;            // owned rows + 2 x ghost rows
+  int count_first, count_end;
   int y_periodic;
-  int y0_global, ny_global;    // global row of the first owned row; global grid height
+  int y0s_global, ny_global;   // global row of storage row 0 (may be negative: a rank's bottom ghost rows wrap); global grid height
   int tiles_x;
   int tile_begin, tile_count, tile_begin2, tile_count2;   // tile ranges of this launch (second may be empty)
   int ntiles_total;            // stride of partials_out
@@ -136,7 +144,8 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [9][kCells], then [K][kWaves] doubles
   double* red = reinterpret_cast<double*>(lds + 9 * kCells);
   // per x-pair of the frame, written by sub-step 1 and read by the in-LDS sub-steps (which then need no
-  // grid coordinates at all): bits 0-1 obstacle bits, 2 owned, 3 on the accelerate row, 4 computed
+  // grid coordinates at all): bits 0-1 obstacle bits, 2 owned (kept: written to the destination grid), 3 on the accelerate row,
+  // 4 computed, 5 counted (owned by this partition: enters the per-step sums)
   uint8_t* pair_flags = reinterpret_cast<uint8_t*>(red + K * kWaves);
   const int tid = threadIdx.x;
 
@@ -171,9 +180,10 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int x0 = tx * TX;
-  const int sy0 = a.ghost + ty * TY;              // storage row of the tile's first owned row
+  const int sy0 = a.row_first + ty * TY;          // storage row of the tile's first row
   const int nx = a.nx;
-  const int rows_storage = a.rows_owned + 2 * a.ghost;
+  const int rows_storage = a.rows_storage;
+  const int row_end = a.row_first + a.rows_compute;   // first storage row past the rows this launch computes
   const int tile_row_base = sy0 * nx;               // block-uniform: a scalar multiply
   const int grid_cells = rows_storage * nx;
   constexpr int ksteps = K;
@@ -185,13 +195,13 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   // does the LDS frame of this tile meet the global accelerate row ny-2 at all ?  (block-uniform)
   bool tile_accel;
   {
-    int d = (a.accel_row - (a.y0_global + ty * TY - EY)) % a.ny_global;     // frame row 0 is global row y0 + ty*TY - EY
+    int d = (a.accel_row - (a.y0s_global + sy0 - EY)) % a.ny_global;        // frame row 0 is storage row sy0 - EY
     if (d < 0) d += a.ny_global;
     tile_accel = d < G::H || a.ny_global < G::H;
   }
   // storage row -> does it hold the global accelerate row ny-2 ?
   auto on_accel_row = [&](int sr) {
-    int g = a.y0_global + sr - a.ghost;
+    int g = a.y0s_global + sr;
     if (g < 0) g += a.ny_global; else if (g >= a.ny_global) g -= a.ny_global;
     return g == a.accel_row;
   };
@@ -204,7 +214,10 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
     // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
     const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + TY + EY + 1 <= rows_storage &&
-                       sy0 + TY <= a.ghost + a.rows_owned;
+                       sy0 + TY <= row_end;
+    // does every row of the tile count in the sums ?  (block-uniform; false only for the first / last tile rows of a launch that
+    // also computes ghost rows)
+    const bool all_counted = sy0 >= a.count_first && sy0 + TY <= a.count_end;
 #pragma unroll 1
     for (int i = tid; i < np; i += kLanes) {
       const int ry = i / wp, rp = i - ry * wp;
@@ -260,15 +273,17 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
       f2 out[9];
       // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
       // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
+      const int srow = sy0 + fy - EY;                                   // the pair's storage row before any periodic wrap
       const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
-                         (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.ghost + a.rows_owned));
+                         (inner || (x0 + fx - EX < nx && srow < row_end));
+      const bool counted = owned && (all_counted || (srow >= a.count_first && srow < a.count_end));
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
-      acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, owned ? mbits : 3u, out, acc_lo[0]);
+      acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, counted ? mbits : 3u, out, acc_lo[0]);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, fy * W, fx, out[k]);
-        pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u);
+        pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u | (counted ? 32u : 0u));
       } else if (owned) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], &at_byte<f2>(a.dstk[k], o_here));
@@ -323,9 +338,10 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
           p[6] = f2{lds[6 * kCells + cs - W], lds[6 * kCells + cs - W + WH + 1]};
           p[7] = f2{lds[7 * kCells + cs + W], lds[7 * kCells + cs + W + WH + 1]};
           const bool owned = lane_on && (fl & 4u);
+          const bool counted = lane_on && (fl & 32u);
           float term_lo = 0.0f;
           const double term = finish_pair_lo<TERMS>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
-                                                    owned ? (fl & 3u) : 3u, outs, term_lo);
+                                                    counted ? (fl & 3u) : 3u, outs, term_lo);
 #pragma unroll
           for (int m = 1; m < K; ++m)
             if (m == j - 1) { acc[m] += term; acc_lo[m] += term_lo; }

@@ -17,6 +17,11 @@ struct P2PWindowHeader {                 // start of every rank's exported windo
   unsigned long long halo_parity[4];     // [2*dir + (epoch & 1)]: the pusher's grid parity for that epoch (lock-step check).  A pusher
                                          // may run ONE epoch ahead of the waiter, never two: a slot per epoch parity is not overwritten early
   unsigned long long reduce_flag[64];    // [r]: rank r's sums of reduce round N are in my slot r
+  unsigned long long halo_ack[2];        // [0]: my SOUTH neighbour has finished every launch that reads or writes its ghost rows of the epochs before
+                                         // this one and is about to push: its ghost rows may be written for this epoch; [1]: NORTH.  The two grids
+                                         // double-buffered the ghost rows only as long as every exchange was followed by ONE launch (rounds 1-3): a
+                                         // group of two launches returns to the grid it started from, and the rows of epoch e+1 would land in the
+                                         // rows a neighbour still reads for epoch e.
 };
 constexpr size_t kP2PHeaderBytes = 4096;
 static_assert(sizeof(P2PWindowHeader) <= kP2PHeaderBytes, "window header");
@@ -37,6 +42,8 @@ struct P2PPushArgs {
   // per macro-step is what a 1024 x 128-row partition notices (20 % of its step)
   const unsigned long long* wait_flags;  // my halo_flag[2], or null: push only
   const unsigned long long* wait_parity; // my halo_parity[4]
+  unsigned long long* ack[2];            // [0]: the south neighbour's halo_ack[1] (I am ITS north neighbour); [1]: the north neighbour's halo_ack[0]
+  const unsigned long long* wait_ack;    // my halo_ack[2]
   long long timeout_ticks;
   int* err;
 };
@@ -44,8 +51,9 @@ struct P2PPushArgs {
 // Polls are RELAXED system-scope loads of the uncached window (an acquire load per poll would invalidate this XCD's
 // caches on every iteration, under the feet of the launch running beside it); ONE acquire fence follows the last
 // of them.  What the flags guard is read by a later kernel of the stream in any case.
+// acquire = false: nothing the flags guard is READ afterwards (the "ready" words, which only hold back this rank's stores).
 __device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, const unsigned long long* parity_words, int nflags, unsigned long long epoch,
-                                               unsigned long long parity, long long timeout_ticks, int* err)
+                                               unsigned long long parity, long long timeout_ticks, int* err, bool acquire = true)
 {
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   const long long t0 = wall_clock64();
@@ -62,7 +70,7 @@ __device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, 
       return;
     }
   }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);                     // system scope
+  if (acquire) __atomic_thread_fence(__ATOMIC_ACQUIRE);        // system scope
 }
 
 // My first K owned rows -> the south neighbour's top ghost rows, my last K owned rows -> the north
@@ -75,8 +83,19 @@ constexpr int kP2PPushBlocks = 64;
 
 __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, int nx)
 {
-  const int per_plane = a.nfloats / 2;                         // float2's of one plane's K rows (nx even)
-  const int total = per_plane * 18;
+  // "Ready for epoch e": this kernel follows, in its stream, every launch of mine that touches my ghost rows of the earlier epochs.
+  // EVERY block says so (the same value into the same two words) and then waits until both neighbours have said it to me — so
+  // no block waits for a block of its own launch, and nobody waits before having spoken: a ring of ranks cannot dead-lock here.
+  __shared__ int go;
+  if (threadIdx.x == 0) {
+    for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ack[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    p2p_wait_flags(a.wait_ack, nullptr, 2, a.epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
+    go = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
+  }
+  __syncthreads();
+  const bool ok = go != 0;                                     // a neighbour never got here: store nothing into its rows, raise nothing
+  const int per_plane = a.nfloats / 2;                         // float2's of one plane's rows (nx even)
+  const int total = ok ? per_plane * 18 : 0;
   // four independent loads in flight per lane, then their stores: the kernel is a chain of memory round trips
   // (a 1024 x 4-row message is 295 KB: one pass), not a bandwidth problem
   constexpr int kUnroll = 4;
@@ -108,12 +127,14 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
     const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == gridDim.x - 1) {                               // the last block raises the flags
       __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int d = 0; d < 2; ++d) __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __builtin_amdgcn_s_waitcnt(0);                           // parity words before flags (both write-through)
-      for (int d = 0; d < 2; ++d) __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (ok && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {   // (a block that timed out stored nothing)
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);                         // parity words before flags (both write-through)
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     // my own push does not depend on this wait, so a ring of ranks that all sit here cannot dead-lock: every
-    // rank's flags are raised by blocks that never wait
+    // rank's flags are raised by blocks that never wait for rows
     if (blockIdx.x == 0 && a.wait_flags) p2p_wait_flags(a.wait_flags, a.wait_parity, 2, a.epoch, a.parity, a.timeout_ticks, a.err);
   }
 }

@@ -113,6 +113,21 @@ int lbm_plan_next(int K, int four_rows, int tail4, int left)
   return k;
 }
 
+// The launches between two halo exchanges of a partitioned run ("a group"): the next launches by lbm_plan_next for as long as their
+// steps add up to at most `ghost` (the first launch of a group advances the ghost rows the later ones read), `group_max` launches at most.
+int lbm_plan_group(int K, int ghost, int group_max, int left, int* steps, int cap)
+{
+  if (K < 1 || K > 4 || ghost < K || group_max < 1 || left < 0 || cap < 0 || (cap > 0 && !steps)) { lbm_internal::set_error("lbm_plan_group: bad argument"); return -1; }
+  int n = 0, used = 0;
+  while (left > 0 && n < group_max) {
+    const int k = lbm_plan_next(K, ghost >= 4 ? 1 : 0, 1, left);
+    if (used + k > ghost) break;
+    if (n < cap) steps[n] = k;
+    ++n; used += k; left -= k;
+  }
+  return n;
+}
+
 int lbm_plan_steps(int K, int four_rows, int n_steps, int* steps, int cap)
 {
   if (K < 1 || K > 4 || n_steps < 0 || cap < 0 || (cap > 0 && !steps)) { lbm_internal::set_error("lbm_plan_steps: bad argument"); return -1; }

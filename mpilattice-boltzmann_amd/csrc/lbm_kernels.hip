@@ -107,6 +107,7 @@ struct lbm_ctx {
   bool self_periodic = true;
   int accel_row = -1;
   int ghost = 0;             // storage rows below / above the owned rows (K-step kernels of a row-partitioned run)
+  int group_max = 1;         // most launches a partitioned run makes per halo exchange (a group: their steps add up to <= ghost)
   bool nt_stores = false;
   bool fast_avvels = false;  // LBM_FLAG_FAST_AVVELS: float sum|u| terms in lbm_multi_kernel / lbm_tile_kernel
   int multi_terms = kTermsCompensated;   // lbm_multi_kernel's form of the terms (kernels/common.h): LBM_FLAG_FAST_AVVELS / LBM_FLAG_EXACT_AVVELS
@@ -311,22 +312,26 @@ void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, in
   else launch_multi_kg<K, kGeomStd>(blocks, s, a, terms);
 }
 
-// Tiles of a launch that makes `k` steps: the tile height depends on k (kernels/multi.h multi_ty).
-int multi_tile_rows(const lbm_ctx* c, int k) { return (c->nyl + multi_ty(k, c->multi_geom) - 1) / multi_ty(k, c->multi_geom); }
-int multi_tiles_for(const lbm_ctx* c, int k) { return c->multi_tiles_x * multi_tile_rows(c, k); }
+// Tiles of a launch that makes `k` steps on the owned rows and `ext` more rows on each side (ext > 0: a launch of a partitioned
+// run that is followed by `ext` more steps before the next halo exchange): the tile height depends on k (kernels/multi.h multi_ty).
+int multi_tile_rows(const lbm_ctx* c, int k, int ext = 0) { return (c->nyl + 2 * ext + multi_ty(k, c->multi_geom) - 1) / multi_ty(k, c->multi_geom); }
+int multi_tiles_for(const lbm_ctx* c, int k, int ext = 0) { return c->multi_tiles_x * multi_tile_rows(c, k, ext); }
 
-// One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps.
-void launch_multi(lbm_ctx* c, int ksteps, bool accel_last, int t0, int n0, int t1, int n1, bool fold, hipStream_t s)
+// One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps of the owned rows and `ext`
+// ghost rows on each side (tile row 0 starts at storage row ghost - ext).
+void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int n0, int t1, int n1, bool fold, hipStream_t s)
 {
   MultiArgs a{};
   a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
   for (int k = 0; k < 9; ++k) { a.srck[k] = a.src + k * c->ps; a.dstk[k] = a.dst + k * c->ps; }
   a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx;
-  a.rows_owned = c->nyl; a.ghost = c->ghost; a.y_periodic = c->self_periodic ? 1 : 0;
-  a.y0_global = c->y0; a.ny_global = c->p.ny;
+  a.row_first = c->ghost - ext; a.rows_compute = c->nyl + 2 * ext; a.rows_storage = c->nyl + 2 * c->ghost;
+  a.count_first = c->ghost; a.count_end = c->ghost + c->nyl;
+  a.y_periodic = c->self_periodic ? 1 : 0;
+  a.y0s_global = c->y0 - c->ghost; a.ny_global = c->p.ny;
   a.tiles_x = c->multi_tiles_x;
   a.tile_begin = t0; a.tile_count = n0; a.tile_begin2 = t1; a.tile_count2 = n1;
-  a.ntiles_total = multi_tiles_for(c, ksteps);
+  a.ntiles_total = multi_tiles_for(c, ksteps, ext);
   a.omega = c->p.omega; a.accel_w1 = c->accel_w1; a.accel_w2 = c->accel_w2;
   a.accel_row = c->p.ny - 2; a.accel_last = accel_last ? 1 : 0;
   a.partials_out = c->partials[c->parity];
@@ -529,7 +534,7 @@ int ensure_graph(lbm_ctx* c, hipStream_t s)
 static bool macro_eligible(const lbm_params* p, int rows, unsigned flags)
 {
   // the multi kernel addresses a plane with 32-bit byte offsets: < 2^30 storage cells
-  const bool fits_u32 = static_cast<size_t>(p->nx) * (rows + 2 * kMaxMultiSteps) < (size_t(1) << 30);
+  const bool fits_u32 = static_cast<size_t>(p->nx) * (rows + 2 * kMaxGhost) < (size_t(1) << 30);
   return !(flags & LBM_FLAG_ONE_STEP) && rows >= 2 * kMTY && fits_u32 && p->nx < (1 << 23) && (p->nx % kMTX == 0 || (p->nx % 2 == 0 && p->nx >= 2 * kMTX));
 }
 
@@ -545,15 +550,25 @@ static int macro_k_for(size_t max_cells)
   return std::min(std::max(tune_env("LBM_TUNE_MACRO_K", 4), 0), kMaxMultiSteps);
 }
 
-// Ghost rows kept on each side of a K-step partition.  One more than K at K = 3: a run whose step count 3 does not
-// divide then ends in 3s and 4s like lbm_run's (a K = 2 macro-step costs 140 us where two thirds of a K = 3 one
-// would be 98, on 8192 x 1024 rows), and a 4-step launch only needs the fourth row to be there.  The exchange
-// moves the rows the NEXT macro-step needs (peer-to-peer loop) or all `ghost` rows (RCCL loop).
+// Ghost rows kept on each side of a K-step partition, and with them how often it exchanges: the launches between two exchanges (a
+// GROUP) make at most `ghost` steps together.  Round 4: 2 K rows, one exchange per TWO launches — the first launch of a group also
+// advances `ext` = (steps of the second) ghost rows on each side from the exchanged rows (under 1 % more cells at 1024 rows), so the
+// second is one launch over all tiles that reads no exchanged row: no interior / edge split, no push, no wait, no join.  Rounds 1-3 kept
+// K rows (4 at K = 3) and exchanged before every launch.  K = 3: 8 rows as well (3 + 4, 4 + 4, 3 + 3): step counts 3 does not divide
+// end in 3s and 4s, as lbm_run's.  LBM_TUNE_MACRO_GHOST overrides (0 or anything below K: K rows, one launch per exchange).
+// The exchange moves the rows the NEXT group needs (peer-to-peer loop) or all `ghost` rows (RCCL loop).
 static int macro_ghost_for(int k)
 {
   if (k <= 0) return 0;
-  const int by_k = k == 3 ? 4 : k;
-  return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_k), k), kMaxMultiSteps);
+  const int by_k = k == 3 ? 8 : 2 * k;
+  return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_k), k), kMaxGhost);
+}
+
+// Most launches per exchange: what the ghost rows allow (LBM_TUNE_MACRO_GROUP caps it; 1 = rounds 1-3's loop on any number of ghost rows).
+static int macro_group_for(int k, int ghost)
+{
+  if (k <= 0) return 1;
+  return std::min(std::max(tune_env("LBM_TUNE_MACRO_GROUP", std::max(ghost / k, 1)), 1), kMaxGroup);
 }
 
 // Geometry of lbm_multi_kernel's launches by partition size.  Width: 64 x 16 tiles for the bandwidth-bound grids; 32 x 16 where 64 x 16
@@ -652,18 +667,19 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->ncells = static_cast<size_t>(p->nx) * ny_local;
   // K-step mode of a row-partitioned run: K ghost rows on each side of the owned rows, refreshed by the
   // neighbours every K steps, all steps done by lbm_multi_kernel (lbm_macro_* calls)
-  const bool fits_u32 = static_cast<size_t>(p->nx) * (ny_local + 2 * kMaxMultiSteps) < (size_t(1) << 30);
+  const bool fits_u32 = static_cast<size_t>(p->nx) * (ny_local + 2 * kMaxGhost) < (size_t(1) << 30);
   if (forced_k > 0) {
-    if (self_periodic || !obstacles_window || forced_k > kMaxMultiSteps || forced_ghost < forced_k || forced_ghost > kMaxMultiSteps ||
+    if (self_periodic || !obstacles_window || forced_k > kMaxMultiSteps || forced_ghost < forced_k || forced_ghost > kMaxGhost ||
         !macro_eligible(p, ny_local, flags)) {
       lbm_internal::set_error("lbm_create_rank: partition cannot run the K-step mode its layout asks for");
       delete c;
       return 1;
     }
     c->multi_K = forced_k; c->ghost = forced_ghost;
+    c->group_max = macro_group_for(forced_k, forced_ghost);
   } else if (forced_k < 0 && !self_periodic && obstacles_global && macro_eligible(p, ny_local, flags)) {
     const int k = macro_k_for(c->ncells);
-    if (k > 0) { c->multi_K = k; c->ghost = macro_ghost_for(k); }
+    if (k > 0) { c->multi_K = k; c->ghost = macro_ghost_for(k); c->group_max = macro_group_for(k, c->ghost); }
   }
   c->multi_tail4 = tune_env("LBM_TUNE_MULTI_TAIL4", 1) != 0;
   c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
@@ -764,7 +780,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
-    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
+    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + 2 * c->ghost + kMinMultiTY - 1) / kMinMultiTY) + 1);
   } else if (!c->tile_kernel && self_periodic && fits_u32 && p->nx < (1 << 23) &&      // (24-bit row multiplies in lbm_multi_kernel)
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
@@ -858,6 +874,7 @@ int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, l
   if (partitioned && macro_eligible(p, lo, flags) && macro_eligible(p, hi, flags))
     out->macro_k = macro_k_for(static_cast<size_t>(p->nx) * hi);
   out->ghost = macro_ghost_for(out->macro_k);
+  out->group = macro_group_for(out->macro_k, out->ghost);
   return 0;
 }
 
@@ -916,7 +933,7 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     hipEvent_t pb = prof_stamp(c, s);
     const bool sweep = c->sweep_R > 0 && k == 3;
     if (sweep) launch_sweep(c, /*accel_last=*/t + k < n_steps, s);
-    else launch_multi(c, k, /*accel_last=*/t + k < n_steps, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/true, s);
+    else launch_multi(c, k, 0, /*accel_last=*/t + k < n_steps, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/true, s);
     if (c->profile) c->prof_launches.push_back({k, pb, prof_stamp(c, s)});
     c->n_prev = sweep ? (c->p.nx / kSTX) * c->sweep_nseg : multi_tiles_for(c, k); c->n_prev_vecs = k;
     c->parity ^= 1;
@@ -1249,33 +1266,83 @@ int lbm_macro_prepare(lbm_ctx* c, int n_steps, void* stream)
   return begin_run(c, n_steps, pick_stream(c, stream));
 }
 
-static int macro_k(const lbm_ctx* c) { return next_multi_k(c, c->run_steps - c->run_done); }
+// The launches between two halo exchanges of a partitioned run (a group): next_multi_k's launches for as long as their steps add
+// up to at most the ghost rows, group_max at most.  Launch i of a group advances, besides the owned rows, ext(i) = the steps of the
+// launches AFTER it in the group ghost rows on each side: what those launches read in place of exchanged rows.
+struct GroupPlan {
+  int n = 0, total = 0;
+  int k[kMaxGroup] = {};
+  int ext(int i) const { int e = 0; for (int j = i + 1; j < n; ++j) e += k[j]; return e; }
+};
+static GroupPlan plan_group(const lbm_ctx* c, int left)
+{
+  GroupPlan g;
+  while (left > 0 && g.n < c->group_max && g.n < kMaxGroup) {
+    const int k = next_multi_k(c, left);
+    if (g.n > 0 && g.total + k > c->ghost) break;
+    g.k[g.n++] = k; g.total += k; left -= k;
+  }
+  return g;
+}
+static GroupPlan macro_group(const lbm_ctx* c) { return plan_group(c, c->run_steps - c->run_done); }
 
-int lbm_macro_next_steps(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run_done < c->run_steps) ? macro_k(c) : 0; }
+int lbm_macro_next_steps(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run_done < c->run_steps) ? macro_group(c).total : 0; }
+int lbm_macro_next_launches(const lbm_ctx* c) { return (c && c->ghost > 0 && c->run_done < c->run_steps) ? macro_group(c).n : 0; }
 
-// Tile rows of a K-step partition: row 0 and the top `top_edge_rows` rows read ghost rows (edge launch,
-// after the exchange); the `interior_rows` rows between them do not.  The top edge is two tile rows
-// when the last one holds fewer owned rows than a launch makes steps (the ring of the row below then reaches the ghosts).
-struct MacroRows { int interior_rows, top_edge_rows; };
-static MacroRows macro_rows(const lbm_ctx* c, int k)            // k = steps of the launch: the tile height follows it
+// Tile rows of a launch of k steps that also advances `ext` ghost rows per side (tile row 0 starts at storage row ghost - ext): the
+// first `bottom_edge_rows` and the last `top_edge_rows` tile rows read exchanged rows (edge launch, after the exchange); the
+// `interior_rows` between them do not: the rows they need — their own, k below and k above — are owned rows.  (The last tile row
+// may hold fewer rows than a launch makes steps: the ring of the row below then reaches the ghost rows, and the top edge is two rows.)
+struct MacroRows { int bottom_edge_rows, interior_rows, top_edge_rows; };
+static MacroRows macro_rows(const lbm_ctx* c, int k, int ext = 0)
 {
   const int ty = multi_ty(k, c->multi_geom);
-  const int nty = (c->nyl + ty - 1) / ty;
-  const int last_rows = c->nyl - (nty - 1) * ty;
-  int top = last_rows < c->ghost ? 2 : 1;                  // (ghost = the most steps a launch of this partition makes)
-  top = std::min(top, nty - 1);
-  return {nty - 1 - top, top};
+  const int first = c->ghost - ext, rows = c->nyl + 2 * ext;
+  const int nty = (rows + ty - 1) / ty;
+  const int lo = c->ghost, hi = c->ghost + c->nyl;                // the owned rows [lo, hi)
+  int b = 0, t = 0;
+  while (b < nty && first + b * ty - k < lo) ++b;
+  while (t < nty - b && std::min(first + (nty - t) * ty, first + rows) - 1 + k >= hi) ++t;
+  return {b, nty - b - t, t};
+}
+
+// The launches of a group, called by both native loops and by the split-phase entry points below.
+static void launch_group_interior(lbm_ctx* c, const GroupPlan& g, bool more_after_group, hipStream_t s)
+{
+  const int k = g.k[0], ext = g.ext(0);
+  const MacroRows r = macro_rows(c, k, ext);
+  launch_multi(c, k, ext, /*accel_last=*/g.n > 1 || more_after_group, r.bottom_edge_rows * c->multi_tiles_x, r.interior_rows * c->multi_tiles_x, 0, 0,
+               /*fold=*/c->n_prev > 0, s);
+}
+static void launch_group_edge(lbm_ctx* c, const GroupPlan& g, bool more_after_group, hipStream_t s)
+{
+  const int k = g.k[0], ext = g.ext(0);
+  const MacroRows r = macro_rows(c, k, ext);
+  launch_multi(c, k, ext, /*accel_last=*/g.n > 1 || more_after_group, 0, r.bottom_edge_rows * c->multi_tiles_x,
+               (r.bottom_edge_rows + r.interior_rows) * c->multi_tiles_x, r.top_edge_rows * c->multi_tiles_x, /*fold=*/c->n_prev > 0, s);
+}
+static void launch_group_whole(lbm_ctx* c, const GroupPlan& g, int i, bool more_after_group, hipStream_t s)   // launch i of the group over all its tiles
+{
+  launch_multi(c, g.k[i], g.ext(i), /*accel_last=*/i + 1 < g.n || more_after_group, 0, multi_tiles_for(c, g.k[i], g.ext(i)), 0, 0, /*fold=*/c->n_prev > 0, s);
+}
+// state flip after launch i of a group (d2q9-bgk.c:376-378)
+static void group_launch_done(lbm_ctx* c, const GroupPlan& g, int i, int launches)
+{
+  c->n_prev = multi_tiles_for(c, g.k[i], g.ext(i));
+  c->n_prev_vecs = g.k[i];
+  c->parity ^= 1;
+  c->cur ^= 1;
+  c->run_done += g.k[i];
+  c->ev_tile_launches += launches;
 }
 
 int lbm_macro_interior(lbm_ctx* c, void* stream)
 {
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_interior: not a K-step context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_interior: no steps left; call lbm_macro_prepare"); return 1; }
-  const int k = macro_k(c);
-  const MacroRows r = macro_rows(c, k);
-  if (r.interior_rows > 0) {   // tile rows whose K-ring stays inside the owned rows
-    launch_multi(c, k, c->run_done + k < c->run_steps, c->multi_tiles_x, c->multi_tiles_x * r.interior_rows, 0, 0,
-                 /*fold=*/c->n_prev > 0, pick_stream(c, stream));
+  const GroupPlan g = macro_group(c);
+  if (macro_rows(c, g.k[0], g.ext(0)).interior_rows > 0) {   // tile rows whose rings stay inside the owned rows
+    launch_group_interior(c, g, c->run_done + g.total < c->run_steps, pick_stream(c, stream));
     HIP_TRY(hipGetLastError());
     c->n_prev = 0;   // folded by this launch's block 0
   }
@@ -1286,11 +1353,9 @@ int lbm_macro_edge(lbm_ctx* c, void* stream)
 {
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_edge: not a K-step context"); return 1; }
   if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_edge: no steps left; call lbm_macro_prepare"); return 1; }
-  const int k = macro_k(c);
-  const MacroRows r = macro_rows(c, k);
-  // whichever of the two launches of a macro-step comes first folds the previous macro-step's sums
-  launch_multi(c, k, c->run_done + k < c->run_steps, 0, c->multi_tiles_x, (1 + r.interior_rows) * c->multi_tiles_x,
-               r.top_edge_rows * c->multi_tiles_x, /*fold=*/c->n_prev > 0, pick_stream(c, stream));
+  const GroupPlan g = macro_group(c);
+  // whichever of the two launches of a macro-step comes first folds the previous launch's sums
+  launch_group_edge(c, g, c->run_done + g.total < c->run_steps, pick_stream(c, stream));
   HIP_TRY(hipGetLastError());
   c->n_prev = 0;
   return 0;
@@ -1299,14 +1364,17 @@ int lbm_macro_edge(lbm_ctx* c, void* stream)
 int lbm_macro_finish(lbm_ctx* c, void* stream)
 {
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_finish: not a K-step context"); return 1; }
+  if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_finish: no steps left; call lbm_macro_prepare"); return 1; }
   hipStream_t s = pick_stream(c, stream);
-  const int k = macro_k(c);
-  c->n_prev = multi_tiles_for(c, k);
-  c->n_prev_vecs = k;
-  c->parity ^= 1;
-  c->cur ^= 1;
-  c->run_done += k;
-  c->ev_tile_launches += 2;
+  const GroupPlan g = macro_group(c);
+  const bool more = c->run_done + g.total < c->run_steps;
+  group_launch_done(c, g, 0, 2);
+  // the rest of the group: launches over all tiles that read the ghost rows the first one advanced — no exchange in between
+  for (int i = 1; i < g.n; ++i) {
+    launch_group_whole(c, g, i, more, s);
+    HIP_TRY(hipGetLastError());
+    group_launch_done(c, g, i, 1);
+  }
   if (c->run_done == c->run_steps) {
     HIP_TRY(hipEventRecord(c->ev_end, s));
     c->ev_launches = c->ev_tile_launches;

@@ -2,19 +2,28 @@
 // Included at the end of lbm_kernels.hip: it drives the K-step launches of a context directly
 // (launch_multi, begin_run, fold_last) and owns the streams / events / mapped peer memory of one rank.
 //
-// Per macro-step (k steps: K, or 3s and 4s — next_multi_k) of one rank, reference lines d2q9-bgk.c:
+// Per GROUP of launches (plan_group: the launches next_multi_k plans — K steps each, 3s and 4s at the end — for as long as their steps
+// add up to at most the ghost rows; two 4-step launches on 8 ghost rows by default) of one rank, reference lines d2q9-bgk.c:
 //
-//   compute stream                    edge stream
-//   ──────────────                    ───────────
-//   wait(edge rows m-1)               push kernel: my edge rows of the current state -> neighbours' ghost rows,
-//   interior tiles m      (:350)                   flags := epoch(m)                    MPI_Startall (:327)
-//   record(interior m)                             then wait: both neighbours' flags >= epoch(m)   MPI_Waitall (:364)
-//                                     wait(interior m-1)
-//                                     edge tile rows m                        (:365-366)
-//                                     record(edge rows m)
+//   compute stream                         edge stream
+//   ──────────────                         ───────────
+//   interior tiles of launch 0   (:350)    push kernel: "ready" to both neighbours, wait for theirs; my first / last r owned rows
+//                                                       (r = the steps of the group) of the current state -> neighbours' ghost rows,
+//                                                       flags := epoch                          MPI_Startall (:327)
+//                                                       then wait: both neighbours' flags >= epoch   MPI_Waitall (:364)
+//                                          edge tile rows of launch 0              (:365-366)
+//   wait(edge rows)                        record(edge rows)
+//   launch 1 ... over ALL tiles: reads
+//     the ghost rows launch 0 advanced,
+//     no exchanged row
+//   record(group done)                     wait(group done); push for the next group
 //
-// Small partitions (< 2 M cells) run everything on the compute stream, two kernels per macro-step — ONE launch
-// over all tiles, then the push + wait kernel: there the two cross-queue waits cost more than the overlap hides.
+// Launch 0 computes, besides the owned rows, ext = (steps of the later launches) ghost rows on each side from the exchanged rows;
+// the later launches are plain launches over all tiles.  With one launch per group (ghost rows = K: rounds 1-3's loop) the push
+// follows the edge launch directly, as the rows it reads are that launch's.
+//
+// Small partitions (< 2 M cells) run everything on the compute stream — the launches of the group, each over all tiles, then
+// the push + wait kernel: there the cross-queue waits cost more than the overlap hides.
 // (Tried and dropped: the push fused into the step launch, the edge tiles storing their rows to the neighbours
 // as well and the last of them raising the flags and waiting — 5.9 instead of 4.3 us/step on a 1024 x 128-row
 // ring: every pushing tile's system-scope fence writes back an L2 that the whole launch is streaming through.)
@@ -33,7 +42,7 @@ constexpr uint32_t kP2PMagic = 0x4C424D50u;   // "LBMP"
 struct P2PBlob {                       // what every rank tells every other rank (POD, <= LBM_P2P_HANDLE_BYTES)
   uint32_t magic, version;
   int32_t pid, device, nranks, rank;
-  int32_t nx, ny, y0, nyl, ghost, K, cur, ipc_ok;
+  int32_t nx, ny, y0, nyl, ghost, K, cur, ipc_ok, group;
   uint64_t ps, window_bytes, reduce_cap;
   uint64_t grid_ptr[2], window_ptr;    // raw device pointers: valid inside the exporting process
   hipIpcMemHandle_t grid_h[2], window_h;
@@ -135,9 +144,9 @@ double p2p_avg_us(const std::vector<P2PSpan>& v, size_t from = 0)
   return n ? s / static_cast<double>(n) : 0.0;
 }
 
-// The k rows of the CURRENT grid that each neighbour needs for its next macro-step of k steps, into the k ghost rows
-// next to its owned rows in the grid of the same parity, flags := epoch; then (same kernel) wait for the neighbours'
-// rows of that epoch to have arrived here.
+// The k rows of the CURRENT grid that each neighbour needs for its next group of launches (k steps in all), into the k ghost rows
+// next to its owned rows in the grid of the same parity — once both neighbours have said that they are done with the rows of the
+// epoch before — flags := epoch; then (same kernel) wait for the neighbours' rows of that epoch to have arrived here.
 int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool exposed = false)
 {
   lbm_ctx* c = t->ctx;
@@ -165,6 +174,9 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
   a.done = t->done;
   a.wait_flags = header_of(t->window)->halo_flag;
   a.wait_parity = header_of(t->window)->halo_parity;
+  a.ack[0] = &header_of(ps.window)->halo_ack[1];         // I am the south neighbour's NORTH neighbour
+  a.ack[1] = &header_of(pn.window)->halo_ack[0];
+  a.wait_ack = header_of(t->window)->halo_ack;
   a.timeout_ticks = t->timeout_ticks;
   a.err = t->err;
   const int work = 18 * (a.nfloats / 2);
@@ -366,7 +378,7 @@ int lbm_p2p_handle(lbm_p2p* t, void* blob_out)
   P2PBlob b{};
   b.magic = kP2PMagic; b.version = LBM_ABI_VERSION;
   b.pid = static_cast<int32_t>(getpid()); b.device = c->device; b.nranks = t->nranks; b.rank = t->rank;
-  b.nx = c->p.nx; b.ny = c->p.ny; b.y0 = c->y0; b.nyl = c->nyl; b.ghost = c->ghost; b.K = c->multi_K; b.cur = c->cur;
+  b.nx = c->p.nx; b.ny = c->p.ny; b.y0 = c->y0; b.nyl = c->nyl; b.ghost = c->ghost; b.K = c->multi_K; b.cur = c->cur; b.group = c->group_max;
   b.ps = c->ps; b.window_bytes = t->window_bytes; b.reduce_cap = t->reduce_cap;
   // IPC handles serve peers in OTHER processes; contexts of one process use the raw pointers, so a
   // runtime that cannot export a handle only rules out the multi-process form (checked at connect)
@@ -406,10 +418,11 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
       lbm_internal::set_error("lbm_p2p_connect: handle " + std::to_string(r) + " is not rank " + std::to_string(r) + " of this run");
       return 1;
     }
-    if (b.nx != c->p.nx || b.ny != c->p.ny || b.K != c->multi_K || b.ghost != c->ghost || b.cur != c->cur || b.reduce_cap != t->reduce_cap) {
+    if (b.nx != c->p.nx || b.ny != c->p.ny || b.K != c->multi_K || b.ghost != c->ghost || b.group != c->group_max || b.cur != c->cur || b.reduce_cap != t->reduce_cap) {
       lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " runs a different layout (nx " + std::to_string(b.nx) + ", ny " +
-                              std::to_string(b.ny) + ", K " + std::to_string(b.K) + ") than rank " + std::to_string(t->rank) + " (K " +
-                              std::to_string(c->multi_K) + "): create every rank with lbm_create_rank");
+                              std::to_string(b.ny) + ", K " + std::to_string(b.K) + ", " + std::to_string(b.ghost) + " ghost rows, " + std::to_string(b.group) +
+                              " launches per exchange) than rank " + std::to_string(t->rank) + " (K " + std::to_string(c->multi_K) + ", " + std::to_string(c->ghost) +
+                              ", " + std::to_string(c->group_max) + "): create every rank with lbm_create_rank");
       return 1;
     }
     if (std::strncmp(b.host, host, sizeof host) != 0) {
@@ -552,74 +565,92 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
   // for it, as in every later macro-step.  Serial schedule: right behind the accelerate kernel with the full
   // complement of blocks (nothing overlaps it).
   unsigned long long epoch = t->epoch + 1;
-  std::vector<P2PSpan> sp_interior, sp_edge, sp_push;
+  std::vector<P2PSpan> sp_interior, sp_edge, sp_push, sp_whole;
+  GroupPlan g = plan_group(c, n_steps);                        // the same sequence of groups on every rank
   {
-    const int k0 = next_multi_k(c, n_steps);
     P2PSpan sp;
     if (t->edge_stream) {
       P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));       // "the accelerated state is ready"
       P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
       sp.begin = p2p_stamp(t, es);
-      if (p2p_push(t, epoch, k0, es)) return bail();
+      if (p2p_push(t, epoch, g.total, es)) return bail();
       sp.end = p2p_stamp(t, es);
     } else {
       sp.begin = p2p_stamp(t, cs);
-      if (p2p_push(t, epoch, k0, cs, /*exposed=*/true)) return bail();
+      if (p2p_push(t, epoch, g.total, cs, /*exposed=*/true)) return bail();
       sp.end = p2p_stamp(t, cs);
     }
     if (t->profile) sp_push.push_back(sp);
   }
   hipEvent_t e_steps0 = p2p_stamp(t, cs);
-  int macro_steps = 0;
-  for (int done = 0; done < n_steps; ++epoch, ++macro_steps) {
-    const int k = next_multi_k(c, n_steps - done);             // K, or 3s and 4s (the same sequence on every rank)
-    const MacroRows rows = macro_rows(c, k);                    // (the tile height follows the steps of the launch)
-    const bool more = done + k < n_steps;
+  int groups = 0, launches = 0, prev_n = 0;
+  bool es_has_waited = true;                                   // the edge stream has waited for the compute stream's last launch (run start: above)
+  for (int done = 0; done < n_steps; ++epoch, ++groups) {
+    const bool more = done + g.total < n_steps;
+    const MacroRows rows = macro_rows(c, g.k[0], g.ext(0));    // (the tile height follows the steps of the launch)
     if (t->edge_stream) {
       if (rows.interior_rows > 0) {                            // :350, beside the exchange
-        if (macro_steps > 0) P2P_RUN_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+        // sources: the previous group's last launch — on this stream when that group had several launches, else its edge rows
+        if (groups > 0 && prev_n == 1) P2P_RUN_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
         P2PSpan sp;
         sp.begin = p2p_stamp(t, cs);
-        launch_multi(c, k, more, c->multi_tiles_x, c->multi_tiles_x * rows.interior_rows, 0, 0, /*fold=*/c->n_prev > 0, cs);
+        launch_group_interior(c, g, more, cs);
         sp.end = p2p_stamp(t, cs);
         if (t->profile) sp_interior.push_back(sp);
         c->n_prev = 0;
       }
       // MPI_Waitall (:364) happened on the device, at the end of the push kernel that precedes this launch
-      if (macro_steps > 0) P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));   // interior m-1: sources of the edge tiles
+      if (!es_has_waited) P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));   // the previous group's launches on the compute stream
       P2PSpan sp;
       sp.begin = p2p_stamp(t, es);
-      launch_multi(c, k, more, 0, c->multi_tiles_x, (1 + rows.interior_rows) * c->multi_tiles_x, rows.top_edge_rows * c->multi_tiles_x,
-                   /*fold=*/c->n_prev > 0, es);               // :365-366
+      launch_group_edge(c, g, more, es);                       // :365-366
       sp.end = p2p_stamp(t, es);
       if (t->profile) sp_edge.push_back(sp);
       c->n_prev = 0;
-      P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));
+      P2P_RUN_TRY(hipGetLastError());
+      P2P_RUN_TRY(hipEventRecord(t->edge_done, es));
+      group_launch_done(c, g, 0, 2);
+      for (int i = 1; i < g.n; ++i) {                          // over all tiles: nothing exchanged is read
+        if (i == 1) P2P_RUN_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+        P2PSpan sw;
+        sw.begin = p2p_stamp(t, cs);
+        launch_group_whole(c, g, i, more, cs);
+        sw.end = p2p_stamp(t, cs);
+        if (t->profile) sp_whole.push_back(sw);
+        P2P_RUN_TRY(hipGetLastError());
+        group_launch_done(c, g, i, 1);
+      }
+      P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));       // "the compute stream's launches of this group"
+      es_has_waited = false;
     } else {
-      P2PSpan sp;
-      sp.begin = p2p_stamp(t, cs);
-      launch_multi(c, k, more, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/c->n_prev > 0, cs);
-      sp.end = p2p_stamp(t, cs);
-      if (t->profile) sp_interior.push_back(sp);
-      c->n_prev = 0;
+      for (int i = 0; i < g.n; ++i) {
+        P2PSpan sp;
+        sp.begin = p2p_stamp(t, cs);
+        launch_group_whole(c, g, i, more, cs);
+        sp.end = p2p_stamp(t, cs);
+        if (t->profile) (i == 0 ? sp_interior : sp_whole).push_back(sp);
+        P2P_RUN_TRY(hipGetLastError());
+        group_launch_done(c, g, i, 1);
+      }
     }
-    P2P_RUN_TRY(hipGetLastError());
-    // the next interior launch needs this macro-step's edge ROWS, not the push that follows them
-    if (t->edge_stream) P2P_RUN_TRY(hipEventRecord(t->edge_done, es));
-    // state flip of lbm_macro_finish (d2q9-bgk.c:376-378)
-    c->n_prev = multi_tiles_for(c, k);
-    c->n_prev_vecs = k;
-    c->parity ^= 1;
-    c->cur ^= 1;
-    c->run_done += k;
-    c->ev_tile_launches += t->edge_stream ? 2 : 1;
-    done += k;
-    if (more) {                                                // MPI_Startall (:327) for the next macro-step
+    launches += g.n;
+    done += g.total;
+    prev_n = g.n;
+    if (more) {                                                // MPI_Startall (:327) for the next group
+      const GroupPlan next = plan_group(c, n_steps - done);
+      if (t->edge_stream) {
+        // the rows to push are the last launch's: its edge rows when the group was one launch and those tile rows hold all
+        // next.total rows of either side (then the push need not wait for the interior launch); else the compute stream's
+        const bool edge_rows_suffice = g.n == 1 && (c->ghost - g.ext(0)) + rows.bottom_edge_rows * multi_ty(g.k[0], c->multi_geom) >= c->ghost + next.total &&
+                                       (c->ghost - g.ext(0)) + (rows.bottom_edge_rows + rows.interior_rows) * multi_ty(g.k[0], c->multi_geom) <= c->ghost + c->nyl - next.total;
+        if (!edge_rows_suffice) { P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0)); es_has_waited = true; }
+      }
       P2PSpan sp;
       sp.begin = p2p_stamp(t, es);
-      if (p2p_push(t, epoch + 1, next_multi_k(c, n_steps - done), es)) return bail();
+      if (p2p_push(t, epoch + 1, next.total, es)) return bail();
       sp.end = p2p_stamp(t, es);
       if (t->profile) sp_push.push_back(sp);
+      g = next;
     }
   }
   t->epoch = epoch - 1;
@@ -645,14 +676,16 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
     ph[3] = p2p_us(e_run0, e_steps0);
     ph[4] = p2p_us(e_steps0, e_steps1);
     ph[5] = p2p_us(e_steps1, t->ev_reduce_end);
-    ph[6] = macro_steps;
-    ph[7] = macro_steps ? ph[4] / macro_steps : 0.0;
+    ph[6] = groups;
+    ph[7] = groups ? ph[4] / groups : 0.0;
     if (sp_interior.size() >= 3) ph[8] = p2p_us(sp_interior[1].begin, sp_interior.back().begin) / static_cast<double>(sp_interior.size() - 2);
     ph[9] = p2p_avg_us(sp_interior);
     ph[10] = p2p_avg_us(sp_edge);
     ph[11] = sp_push.empty() ? 0.0 : p2p_us(sp_push[0].begin, sp_push[0].end);
     ph[12] = p2p_avg_us(sp_push, 1);
     ph[13] = ph[0] - ph[2];
+    ph[14] = launches;
+    ph[15] = p2p_avg_us(sp_whole);
     t->phases_valid = true;
   }
   return 0;
@@ -677,7 +710,7 @@ int lbm_p2p_phases(const lbm_p2p* t, double* values)
 const char* lbm_p2p_phase_name(int i)
 {
   static const char* const names[] = {"host_total", "host_enqueue", "device_span", "setup", "steps", "reduce", "macro_steps", "macro_step_avg",
-                                      "macro_step_steady", "interior_avg", "edge_avg", "push_first", "push_avg", "host_overhead"};
+                                      "macro_step_steady", "interior_avg", "edge_avg", "push_first", "push_avg", "host_overhead", "launches", "whole_avg"};
   return (i >= 0 && i < static_cast<int>(sizeof names / sizeof names[0])) ? names[i] : nullptr;
 }
 
@@ -690,7 +723,8 @@ int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)
     std::snprintf(text, len, "window %s; neighbours %s; one-step mode", t->window_kind, reach);
     return 0;
   }
-  std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d", t->window_kind, reach, t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K);
+  std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d; ghost rows %d; launches per exchange %d", t->window_kind, reach,
+                t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K, t->ctx->ghost, t->ctx->group_max);
   return 0;
 }
 

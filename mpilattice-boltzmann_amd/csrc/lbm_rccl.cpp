@@ -171,15 +171,15 @@ int lbm_comm_destroy(lbm_comm* c)
   return 0;
 }
 
-// K-step mode (contexts from lbm_create_rank / lbm_create_global, lbm_macro_steps() = K > 0): one exchange of the
-// partition's ghost rows (K whole rows of each of the 9 planes; four at K = 3) per macro-step, same three-queue schedule.  By default the 18 row blocks of a
-// direction pair are packed into one message per direction by a small kernel on the exchange stream
-// (fewer, larger messages); LBM_RCCL_PACK=0 sends them straight from the edge rows into the
-// neighbour's ghost rows as 18 + 18 messages.
+// K-step mode (contexts from lbm_create_rank / lbm_create_global, lbm_macro_steps() = K > 0): one exchange of the partition's ghost
+// rows (`ghost` whole rows of each of the 9 planes: 2 K) per GROUP of launches (lbm_macro_next_launches(): two 4-step launches by
+// default), same three-queue schedule for the first launch of the group; the later ones — launches over all tiles that read no
+// exchanged row — are made by lbm_macro_finish on the compute stream.  By default the 18 row blocks of a direction pair are packed into
+// one message per direction by a small kernel on the exchange stream (fewer, larger messages); LBM_RCCL_PACK=0 sends them straight
+// from the edge rows into the neighbour's ghost rows as 18 + 18 messages.
 static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
 {
   lbm_ctx* ctx = c->ctx;
-  const int K = lbm_macro_steps(ctx);
   const size_t n = lbm_macro_halo_floats(ctx), np = lbm_macro_pack_floats(ctx);
   const char* pk = std::getenv("LBM_RCCL_PACK");
   const bool packed = !(pk && pk[0] == '0');              // default: 2 + 2 packed messages; 0 = 18 + 18 direct ones
@@ -188,11 +188,14 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
   LBM_TRY(lbm_macro_prepare(ctx, n_steps, c->compute));   // step-0 accelerate_flow
   HIP_TRY(hipEventRecord(c->edge_done, c->compute));
   HIP_TRY(hipEventRecord(c->interior_done, c->compute));
-  (void)K;
+  int prev_launches = 1;
   for (int done = 0; done < n_steps;) {
-    const int k = lbm_macro_next_steps(ctx);                 // K, fewer at the end, or 3s and 4s (four ghost rows at K = 3)
-    if (k <= 0) { lbm_internal::set_error("lbm_comm_run: the context has no macro-step left"); return 1; }
-    HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));   // the rows to send were written by the last edge launch
+    const int k = lbm_macro_next_steps(ctx);                 // steps until the next exchange: those of the group's launches together
+    const int launches = lbm_macro_next_launches(ctx);
+    if (k <= 0 || launches <= 0) { lbm_internal::set_error("lbm_comm_run: the context has no macro-step left"); return 1; }
+    // the rows to send were written by the last launch of the previous group: its edge launch and whatever ran on the compute stream
+    HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->interior_done, 0));
     if (packed) {
       // gather the 9 planes' rows into one message per direction, exchange 2 + 2 messages, scatter
       LBM_TRY(lbm_macro_pack(ctx, c->side));
@@ -205,34 +208,34 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
       LBM_TRY(lbm_macro_unpack(ctx, c->side));
     } else {
       NCCL_TRY(ncclGroupStart());
-      for (int k = 0; k < LBM_NSPEEDS; ++k) {                // rows straight into the neighbour's ghost rows
-        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
-        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
-        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, k), n, ncclFloat, c->north, c->nccl, c->side));
-        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, k), n, ncclFloat, c->south, c->nccl, c->side));
+      for (int q = 0; q < LBM_NSPEEDS; ++q) {                // rows straight into the neighbour's ghost rows
+        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, q), n, ncclFloat, c->south, c->nccl, c->side));
+        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, q), n, ncclFloat, c->north, c->nccl, c->side));
+        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, q), n, ncclFloat, c->north, c->nccl, c->side));
+        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, q), n, ncclFloat, c->south, c->nccl, c->side));
       }
       NCCL_TRY(ncclGroupEnd());
     }
     HIP_TRY(hipEventRecord(c->halo, c->side));
-    if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+    if (three_queues && prev_launches == 1) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
     LBM_TRY(lbm_macro_interior(ctx, c->compute));
     HIP_TRY(hipStreamWaitEvent(edge_stream, c->halo, 0));
     if (three_queues) HIP_TRY(hipStreamWaitEvent(c->edge, c->interior_done, 0));
     LBM_TRY(lbm_macro_edge(ctx, edge_stream));
     HIP_TRY(hipEventRecord(c->edge_done, edge_stream));
-    if (three_queues) {
-      HIP_TRY(hipEventRecord(c->interior_done, c->compute));
-      if (done + k >= n_steps) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
-    }
+    // the later launches of the group (and the last fold of a run) follow on the compute stream and read the edge rows
+    if (three_queues && (launches > 1 || done + k >= n_steps)) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
     LBM_TRY(lbm_macro_finish(ctx, c->compute));
+    HIP_TRY(hipEventRecord(c->interior_done, c->compute));
     if (c->step_allreduce) {
-      // this macro-step's totals now, and the next macro-step behind their all-reduce (north_star wording)
+      // this group's totals now, and the next group behind their all-reduce (north_star wording)
       if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
       LBM_TRY(lbm_step_fold(ctx, c->compute));
       double* sums_now = static_cast<double*>(lbm_step_sums_device_ptr(ctx)) + done;
       NCCL_TRY(ncclAllReduce(sums_now, sums_now, static_cast<size_t>(k), ncclDouble, ncclSum, c->nccl, c->compute));
     }
     done += k;
+    prev_launches = launches;
   }
   double* sums = static_cast<double*>(lbm_step_sums_device_ptr(ctx));
   if (c->nranks > 1 && !c->step_allreduce) NCCL_TRY(ncclAllReduce(sums, sums, static_cast<size_t>(n_steps), ncclDouble, ncclSum, c->nccl, c->compute));

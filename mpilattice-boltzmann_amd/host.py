@@ -85,7 +85,22 @@ def rank_layout(params: Params, nranks: int, rank: int, flags: int = 0) -> dict:
     lay = _capi.CLayout()
     cp = _cparams(params)
     check(lib.lbm_rank_layout(C.byref(cp), nranks, rank, flags, C.byref(lay)))
-    return {"y0": lay.y0, "ny_local": lay.ny_local, "macro_k": lay.macro_k, "ghost": lay.ghost}
+    return {"y0": lay.y0, "ny_local": lay.ny_local, "macro_k": lay.macro_k, "ghost": lay.ghost, "group": lay.group}
+
+
+def plan_groups(K: int, ghost: int, group_max: int, n_steps: int) -> list[list[int]]:
+    """`lbm_plan_group` over a whole run: the launches between consecutive halo exchanges of a partitioned run, as lists of steps —
+    e.g. K = 4 on 8 ghost rows, 20 steps: [[4, 4], [4, 4], [4]]."""
+    lib = _capi.load_library()
+    out, left = [], n_steps
+    buf = (C.c_int * 8)()
+    while left > 0:
+        n = lib.lbm_plan_group(K, ghost, group_max, left, buf, 8)
+        if n <= 0:
+            raise LbmError(lib.lbm_last_error().decode(errors="replace") if n < 0 else "lbm_plan_group: empty group")
+        out.append([int(buf[i]) for i in range(n)])
+        left -= sum(out[-1])
+    return out
 
 
 def obstacle_window(obstacles: np.ndarray, layout: dict) -> np.ndarray:
@@ -204,6 +219,11 @@ class Partition:
         """Steps of the macro-step about to be made (`lbm_macro_next_steps`): K, fewer at the end of a run, or 3s and
         4s where the partition keeps four ghost rows at K = 3.  0 when no run is in progress."""
         return int(self._lib.lbm_macro_next_steps(self._ctx))
+
+    @property
+    def macro_launches(self) -> int:
+        """Launches of the macro-step about to be made (`lbm_macro_next_launches`): one exchange, then that many launches."""
+        return int(self._lib.lbm_macro_next_launches(self._ctx))
 
     def macro_prepare(self, n_steps: int, stream=None) -> None:
         check(self._lib.lbm_macro_prepare(self._ctx, n_steps, self._stream_ptr(stream)))
@@ -707,7 +727,7 @@ class Simulation:
         if not self._partitioned:
             self.free_cells = count_free_cells(obstacles) if free_cells is None else free_cells
             self.free_cells_inv = np.float32(1.0) / np.float32(self.free_cells)
-            self.layout = {"y0": 0, "ny_local": params.ny, "macro_k": 0, "ghost": 0}
+            self.layout = {"y0": 0, "ny_local": params.ny, "macro_k": 0, "ghost": 0, "group": 1}
             self.ny_local, self.displs = [params.ny], [0]
             self.y0, self.nyl = 0, params.ny
             self.partition = Partition(params, self.free_cells, obstacles, 0, device, flags)

@@ -1,0 +1,73 @@
+#!/bin/bash
+# One GPU-box session = a tag and a list of steps:   gpurun -- 'bash scripts/gpu_session.sh <tag> <step> [<step> ...]'
+# Every step writes under gpurun_out/<tag>/ (merged back by gpurun) and the steps are joined with &&: after a step that
+# fails or times out no further GPU step starts.  A step is `name` or `name:arg` (arg: the rest after the first colon).
+#   tests[:<pytest -k expr>]      the GPU parity suite (or a selection), complete log in pytest.log
+#   smoke                         __graft_entry__.smoke()
+#   rings[:<grids>]               1-rank peer-to-peer rings, ONE PER PROCESS, over the halo depths (LBM_TUNE_MACRO_GHOST) 0 8 12 16 at
+#                                 20 and 200 steps per run — a rank's share of a partitioned run, the wire a self-copy (default grids: 8192x1024 1024x128)
+#   ringsrccl[:<grids>]           the same over the RCCL loop
+#   bench[:<bench.py args>]       bench.py (default: the driver's --steps 20 --warmup 5), the line in bench.json
+#   prof[:<bench.py args>]        rocprofv3 --kernel-trace --stats of bench.py, summary in prof/
+#   pmc:<counters>:<bench args>   one rocprofv3 --pmc pass of bench.py (its own run, no trace flags)
+#   decks                         the four shipped decks through bin/d2q9-bgk
+#   fuzz[:<cases>]                scripts/fuzz_kernels.py
+#   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 LBM_P2P_TIMEOUT_MS=${LBM_P2P_TIMEOUT_MS:-10000}
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+
+ring_lines() {   # $1 exchange, $2 file, $3.. grids
+  local exch=$1 file=$2; shift 2
+  for g in "$@"; do
+    for ghost in 0 8 12 16; do
+      for steps in 20 200; do
+        local rounds=40; [ $steps = 200 ] && rounds=8
+        [ "${g#1024x}" != "$g" ] && rounds=$((rounds * 3))
+        echo "== $exch ring $g, LBM_TUNE_MACRO_GHOST=$ghost, $steps steps per run"
+        LBM_TUNE_MACRO_GHOST=$ghost timeout -k 10 240 python scripts/ab_ring.py --exchange $exch --grid $g --steps $steps --rounds $rounds - 2>&1 | tail -1 || return 1
+      done
+    done
+  done | grep -v amdgpu.ids | tee "$file"
+}
+
+step() {
+  local name=${1%%:*} arg=""
+  [ "$name" != "$1" ] && arg=${1#*:}
+  echo "#### $TAG: $name $arg"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -x -q -k "$arg" > "$OUT/pytest.log" 2>&1
+      else timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; fi
+      local rc=$?; tail -15 "$OUT/pytest.log"; return $rc ;;
+    smoke) timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee "$OUT/smoke.log" ;;
+    rings) ring_lines p2p "$OUT/rings_p2p.txt" ${arg:-8192x1024 1024x128} ;;
+    ringsrccl) ring_lines rccl "$OUT/rings_rccl.txt" ${arg:-8192x1024 1024x128} ;;
+    bench) timeout -k 10 500 python bench.py ${arg:---steps 20 --warmup 5} > "$OUT/bench.json" 2> "$OUT/bench.err"; local rc=$?; tail -c 1500 "$OUT/bench.json"; return $rc ;;
+    prof)
+      rm -rf "$OUT/prof"
+      timeout -k 10 500 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace --output-format csv -- python3 bench.py ${arg:---steps 20 --warmup 5 --no-cpu-baseline --no-variants} > "$OUT/prof_bench.json" 2> "$OUT/prof.err"
+      local rc=$?; find "$OUT/prof" -name '*kernel_stats.csv' | head -1 | xargs -r head -8; find "$OUT/prof" -name '*kernel_trace.csv' -delete; return $rc ;;
+    pmc)
+      local ctr=${arg%%:*} rest=""; [ "$ctr" != "$arg" ] && rest=${arg#*:}
+      local d="$OUT/pmc_$(echo $ctr | tr ' ' '_' | cut -c1-40)"; rm -rf "$d"
+      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py ${rest:---steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-phases --no-power} > "$d.json" 2> "$d.err"
+      local rc=$?; tail -3 "$d.err"; return $rc ;;
+    decks)
+      for d in 128x128 128x256 256x256 1024x1024; do
+        ( cd /tmp && "$GRAFT_REPO_ROOT/mpilattice-boltzmann_amd/bin/d2q9-bgk" "$GRAFT_REPO_ROOT/tests/golden/decks/input_$d.params" "$GRAFT_REPO_ROOT/tests/golden/decks/obstacles_$d.dat" | sed -n '2,3p;6p' | tr '\n' ' '; echo "  [$d]" )
+      done | tee "$OUT/cli_decks.txt" ;;
+    fuzz) timeout -k 10 1000 python scripts/fuzz_kernels.py --cases ${arg:-150} --seed 4 2>&1 | grep -v amdgpu.ids | tail -12 | tee "$OUT/fuzz.log" ;;
+    ab)
+      local libs=${arg%%:*} rest=""; [ "$libs" != "$arg" ] && rest=${arg#*:}
+      timeout -k 10 900 python scripts/ab_libs.py $(echo $libs | tr ',' ' ') $rest 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/ab.txt" ;;
+    *) echo "unknown step $name"; return 2 ;;
+  esac
+}
+
+for s in "$@"; do
+  step "$s" || { echo "#### step $s failed: stopping"; exit 1; }
+done
+echo "#### $TAG done"

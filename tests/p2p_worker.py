@@ -8,7 +8,8 @@ Several cases per launch; rank 0 compares the gathered state with the oracle, bi
 
     python -m torch.distributed.run --nproc-per-node N ... tests/p2p_worker.py '<json list of cases>'
 case = {"nx", "ny", "K" (0 = library default), "schedule" ("edge" | "serial" | ""), "runs": [steps, ...], "p", "seed", "walls",
-        "scatter" (only rank 0 holds the obstacle map), "exchange" ("p2p" | "rccl"), "step_allreduce"}"""
+        "scatter" (only rank 0 holds the obstacle map), "exchange" ("p2p" | "rccl"), "step_allreduce",
+        "ghost", "group" (LBM_TUNE_MACRO_GHOST / _GROUP: ghost rows kept and most launches per halo exchange; default 2 K rows, two launches)}"""
 import json
 import os
 import sys
@@ -36,7 +37,8 @@ def main() -> int:
     for i, c in enumerate(cases):
         exchange = c.get("exchange", "p2p")
         for key, val in (("LBM_TUNE_MACRO_K", c.get("K", 0)), ("LBM_P2P_SCHEDULE", c.get("schedule", "")),
-                         ("LBM_RCCL_SCHEDULE", c.get("schedule", "") if exchange == "rccl" else "")):
+                         ("LBM_RCCL_SCHEDULE", c.get("schedule", "") if exchange == "rccl" else ""),
+                         ("LBM_TUNE_MACRO_GHOST", c.get("ghost", "")), ("LBM_TUNE_MACRO_GROUP", c.get("group", ""))):
             if val:
                 os.environ[key] = str(val)
             else:

@@ -730,8 +730,8 @@ def _k_step_partitions_in_process(lbm, parts, steps, K):
             for part in parts:
                 part.macro_interior(st)
                 part.macro_edge(st)
-            k = parts[0].macro_next                                              # K, or 3s and 4s; the same on every partition
-            assert 1 <= k <= 4 and all(part.macro_next == k for part in parts)
+            k = parts[0].macro_next                                              # steps until the next exchange; the same on every partition
+            assert 1 <= k <= 16 and all(part.macro_next == k for part in parts)
             for part in parts:
                 part.macro_finish(st)
             done += k
@@ -903,13 +903,76 @@ def test_k_step_partitions_with_rows_the_tile_does_not_divide(lbm, oracle, monke
             for part in parts:
                 part.macro_interior(st)
                 part.macro_edge(st)
-            k = parts[0].macro_next                                              # K, or 3s and 4s; the same on every partition
-            assert 1 <= k <= 4 and all(part.macro_next == k for part in parts)
+            k = parts[0].macro_next                                              # steps until the next exchange; the same on every partition
+            assert 1 <= k <= 16 and all(part.macro_next == k for part in parts)
             for part in parts:
                 part.macro_finish(st)
             done += k
         sums = sum(part.step_collect(steps, st) for part in parts)
     tstream.synchronize()
+    cells = np.concatenate([part.get_cells() for part in parts], axis=0)
+    ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    av = sums * np.float64(np.float32(1.0) / np.float32(free))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < 1e-12
+    for part in parts:
+        part.close()
+
+
+# (ghost rows, most launches per exchange): rounds 1-3's loop (K rows, an exchange before every launch); the default (2 K rows, two
+# launches); deeper groups; fewer ghost rows than two launches make steps (single launches on spare rows); a cap below what the rows allow
+GROUPINGS = [("0", ""), ("", ""), ("12", ""), ("16", ""), ("7", ""), ("16", "2"), ("8", "1")]
+
+
+@pytest.mark.parametrize("ghost,group", GROUPINGS)
+@pytest.mark.parametrize("nx,ny,K,exchange,schedule", [(192, 99, 4, "p2p", "edge"), (130, 100, 3, "p2p", "serial"), (256, 131, 4, "rccl", "edge"),
+                                                      (512, 70, 2, "p2p", "edge"), (1024, 300, 4, "p2p", "edge"), (128, 64, 4, "rccl", "serial")])
+def test_groups_of_launches_per_exchange_on_a_ring_of_one(lbm, oracle, monkeypatch, nx, ny, K, exchange, schedule, ghost, group):
+    """One halo exchange per GROUP of launches (d2q9-bgk.c:326-328,364 once per up to `ghost` steps): the first launch of a group also
+    advances the ghost rows the later launches read — rows that belong to the neighbour (here: the rank itself, around the ring) and
+    must not enter this rank's per-step sums.  Both native loops, both schedules, row counts no tile height divides, repeated runs
+    whose step counts leave groups of every length, against the oracle bit for bit."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    monkeypatch.setenv("LBM_P2P_SCHEDULE", schedule)
+    monkeypatch.setenv("LBM_RCCL_SCHEDULE", schedule)
+    if ghost:
+        monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", ghost)
+    if group:
+        monkeypatch.setenv("LBM_TUNE_MACRO_GROUP", group)
+    runs = [20, 11, 1, 29]
+    p = lbm.Params(nx, ny, sum(runs), 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 5 + ny, False)
+    sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange=exchange, strict=True)
+    lay = sim.layout
+    want_ghost = max(min(int(ghost), 16), K) if ghost else (8 if K == 3 else 2 * K)
+    assert sim.loop == exchange and (lay["macro_k"], lay["ghost"]) == (K, want_ghost) and lay["group"] == (int(group) if group else max(want_ghost // K, 1))
+    av = np.concatenate([sim.run(n) for n in runs])
+    cells = sim.local_cells()
+    sim.close()
+    ref_cells, _, ref_exact = oracle.run(p, obst, sum(runs), nthreads=4)
+    assert np.array_equal(bits(cells), bits(ref_cells))
+    assert np.max(np.abs(av - ref_exact) / ref_exact) < AV_EXACT_RTOL
+
+
+@pytest.mark.parametrize("ghost,group", GROUPINGS)
+@pytest.mark.parametrize("nx,ny,size,K", [(256, 200, 3, 4), (1000, 1000, 8, 4), (192, 99, 2, 3), (128, 260, 8, 4), (2048, 1100, 2, 4)])
+def test_groups_of_launches_per_exchange_with_several_partitions(lbm, oracle, monkeypatch, nx, ny, size, K, ghost, group):
+    """The same through the split-phase entry points (exchange of ALL ghost rows by device copies; lbm_macro_interior / _edge, then
+    lbm_macro_finish, which makes the later launches of the group): uneven partitions, the tall geometry (2048 x 1100 on two ranks),
+    per-step sums of each rank over ITS rows only — they must add up to the oracle's to 1e-12."""
+    monkeypatch.setenv("LBM_TUNE_MACRO_K", str(K))
+    if ghost:
+        monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", ghost)
+    if group:
+        monkeypatch.setenv("LBM_TUNE_MACRO_GROUP", group)
+    steps = 31
+    p = lbm.Params(nx, ny, steps, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 5 + ny, False)
+    free = lbm.count_free_cells(obst)
+    lays = [lbm.rank_layout(p, size, r) for r in range(size)]
+    parts = [lbm.Partition(p, free, lbm.obstacle_window(obst, lays[r]), rank_of=(r, size)) for r in range(size)]
+    assert all(part.macro_steps == K for part in parts)
+    sums = _k_step_partitions_in_process(lbm, parts, steps, K)
     cells = np.concatenate([part.get_cells() for part in parts], axis=0)
     ref_cells, _, ref_exact = oracle.run(p, obst, steps, nthreads=4)
     assert np.array_equal(bits(cells), bits(ref_cells))
@@ -1077,10 +1140,13 @@ def test_p2p_ring_of_one(lbm, oracle, digests, monkeypatch, name, steps, K, sche
 P2P_CASES = {
     2: [dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11]), dict(nx=192, ny=99, K=3, schedule="serial", runs=[7, 24]),
         dict(nx=512, ny=70, K=2, schedule="edge", runs=[31], scatter=True), dict(nx=1024, ny=1024, K=0, schedule="", runs=[13, 2], walls=True),
-        dict(nx=256, ny=64, K=1, schedule="serial", runs=[9])],
-    3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
+        dict(nx=256, ny=64, K=1, schedule="serial", runs=[9]),
+        # rounds 1-3's loop (an exchange before every launch), and four launches per exchange on 16 ghost rows
+        dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11], ghost="0"), dict(nx=192, ny=99, K=4, schedule="edge", runs=[37, 20], ghost="16")],
+    3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=4, schedule="edge", runs=[20, 21], ghost="12"), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
         dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True)],
     4: [dict(nx=256, ny=131, K=3, schedule="edge", runs=[31]), dict(nx=128, ny=260, K=4, schedule="serial", runs=[17, 14]),
+        dict(nx=128, ny=260, K=4, schedule="edge", runs=[17, 14], ghost="16", group="3"),
         dict(nx=2048, ny=4100, K=0, schedule="", runs=[7], scatter=True, p=0.005),
         # one-step mode: 12 / 11-row ranks, an odd row length, a 3-row last rank (d2q9-bgk.c:848-849)
         dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=37, ny=45, K=0, schedule="", runs=[19], scatter=True),
@@ -1171,10 +1237,12 @@ def test_bench_on_two_gpus_harvests_every_part(lbm):
     assert out["variants"]["rccl_step_allreduce"]["parity_ok"] is True and out["variants"]["rccl_step_allreduce"]["step_allreduce"] is True
     sec = out["secondary"]["input_1024x1024"]
     assert sec["p2p"]["parity_ok"] is True and sec["rccl"]["parity_ok"] is True
-    assert out["phases"]["max_over_ranks"]["macro_steps"] == 5 and len(out["phases"]["per_rank"]) == 2
+    assert out["phases"]["max_over_ranks"]["macro_steps"] == 3 and out["phases"]["max_over_ranks"]["launches"] == 5 and len(out["phases"]["per_rank"]) == 2
 
 
-@pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge")])
+@pytest.mark.parametrize("nx,ny,size,K,schedule", [(256, 200, 3, 3, "serial"), (130, 100, 2, 4, "serial"), (192, 99, 2, 3, "edge"),
+                                                   # >= 2^20 cells per rank: several tall-geometry contexts (79 KB frames) in one process
+                                                   (2048, 1100, 2, 4, "serial")])
 def test_p2p_partitions_in_one_process(lbm, nx, ny, size, K, schedule):
     """Several ranks of one run as contexts of ONE process (one host thread per rank, as a single-process
     multi-GPU host drives them), connected through plain pointers instead of IPC handles
@@ -1245,7 +1313,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     # the RCCL variants (here: recorded as not usable, the two ranks share this box's one GPU — not a crash), and
     # BASELINE.json config 4, the shipped 1024 x 1024 deck on the same ranks
     ph = out["phases"]
-    assert len(ph["per_rank"]) == 2 and ph["max_over_ranks"]["macro_steps"] == 5            # 20 = 5 x 4
+    assert len(ph["per_rank"]) == 2 and ph["max_over_ranks"]["macro_steps"] == 3 and ph["max_over_ranks"]["launches"] == 5   # 20 = (4 + 4) + (4 + 4) + 4: three exchanges
     for name in ("host_total", "setup", "steps", "reduce", "macro_step_avg", "interior_avg", "push_first", "push_avg", "host_overhead"):
         assert ph["max_over_ranks"][name] > 0, name
     for name in ("rccl", "rccl_step_allreduce"):
@@ -1269,6 +1337,33 @@ def test_cli_drives_several_ranks_from_one_process(lbm, digests, tmp_path, gpus,
     assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
     av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,1"])
+def test_cli_ranks_of_one_process_on_the_tall_geometry(lbm, tmp_path, devices):
+    """The single-process multi-device host (LBM_GPUS=N, one context per rank in ONE process: the reference's `mpirun -np N`,
+    mpi_submit:63) on a deck with >= 2^20 cells per rank, so that every context launches lbm_multi_kernel<4> on 64 x 23 tiles — 79 KB of
+    dynamic LDS, a limit that is raised per DEVICE by lbm_create (a per-process flag once left the second device of such a host at
+    the default).  "0,0": both ranks on this box's GPU.  "0,1": one device per rank — switches itself on with two GPUs.  Against a
+    one-rank run of the same binary: same bytes in final_state.dat and av_vels.dat within the float's own rounding."""
+    import torch
+    if devices == "0,1" and torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    p = lbm.Params(2048, 1100, 44, 10, 0.1, 0.005, 1.85)
+    ppath, opath = lbm.write_synthetic_deck(str(tmp_path), "2048x1100", p, p=0.005, seed=7)
+    outs = {}
+    for tag, extra in (("one", {}), ("two", dict(LBM_GPUS="2", LBM_DEVICES=devices, LBM_P2P_TIMEOUT_MS="20000"))):
+        d = tmp_path / tag
+        d.mkdir()
+        env = {k: v for k, v in os.environ.items() if k not in ("LBM_GPUS", "LBM_DEVICES")}
+        env.update(extra)
+        r = subprocess.run([lbm.CLI_PATH, ppath, opath], cwd=d, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (r.stdout.splitlines(), sha256(d / "final_state.dat"), lbm.checker.load_av_vels(str(d / "av_vels.dat")))
+    assert "(2 GPUs, peer-to-peer halos)" in outs["two"][0][5] and "(1 GPU)" in outs["one"][0][5]
+    assert outs["one"][0][1] == outs["two"][0][1]                       # the Reynolds line
+    assert outs["one"][1] == outs["two"][1]                             # final_state.dat, byte for byte
+    assert np.allclose(outs["one"][2], outs["two"][2], rtol=2e-7, atol=0)
 
 
 def test_observables_path_writes_the_reference_file(lbm, digests, tmp_path):
@@ -1456,7 +1551,8 @@ def test_launch_profile_and_ring_phases(lbm, digests, monkeypatch):
         ph = ring._p2p.phases()
         assert np.max(np.abs(av_r - av_a) / av_a) < AV_EXACT_RTOL
         k = ring.partition.macro_steps
-        assert ph["macro_steps"] == (6 if k == 3 else 5)                 # 4 + 4 + 3 + 3 + 3 + 3, or 5 x 4 (512 x 512: K = 4)
+        assert (ph["macro_steps"], ph["launches"]) == ((3, 6) if k == 3 else (3, 5))   # (4 + 4) + (3 + 3) + (3 + 3), or (4 + 4) + (4 + 4) + 4 (512 x 512: K = 4)
+        assert ph["whole_avg"] > 0                                       # the second launch of a group: all tiles, nothing exchanged
         assert ph["host_total"] >= ph["device_span"] > 0 and abs(ph["setup"] + ph["steps"] + ph["reduce"] - ph["device_span"]) < 0.05 * ph["device_span"] + 5.0
         assert ph["interior_avg"] > 0 and ph["push_first"] > 0 and ph["push_avg"] > 0 and (ph["edge_avg"] > 0) == (schedule == "edge")
         assert abs(ph["host_overhead"] - (ph["host_total"] - ph["device_span"])) < 1e-6

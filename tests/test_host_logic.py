@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lbm):
     assert declared <= exported, declared - exported
     assert declared == set(lbm.EXPORTS), declared ^ set(lbm.EXPORTS)
     lib = lbm.load_library()
-    assert lib.lbm_abi_version() == 3 == lbm._capi.ABI_VERSION
+    assert lib.lbm_abi_version() == 4 == lbm._capi.ABI_VERSION
 
 
 def test_p2p_entry_points_are_exported_by_the_core_library(lbm):
@@ -166,7 +166,8 @@ def test_rank_layout_is_one_decision_for_all_ranks(lbm):
         nyl, dis = lbm.decompose(ny, size)
         assert [l["ny_local"] for l in lays] == nyl and [l["y0"] for l in lays] == dis
         assert len({l["macro_k"] for l in lays}) == 1, lays
-        assert all(l["ghost"] == (4 if l["macro_k"] == 3 else l["macro_k"]) for l in lays)   # four ghost rows at K = 3: runs end in 3s and 4s
+        # 2 K ghost rows, two launches per halo exchange (round 4); nothing to keep in one-step mode
+        assert all((l["ghost"], l["group"]) == ((8, 2) if l["macro_k"] == 4 else (0, 1)) for l in lays)
         k = lays[0]["macro_k"]
         if size == 1:
             assert k == 0                                            # a whole periodic grid needs no ghost rows ...
@@ -589,3 +590,41 @@ def test_only_a_failed_rendezvous_is_ever_run_again():
     assert not again(1, "", "Memory access fault by GPU node-2\n" + gloo)
     assert not again(1, "", gloo + "\n" + summary.format(code=-11))                                  # the first rank to fail died of a signal
     assert not again(1, "", "something else went wrong\n" + summary.format(code=1))                  # no rendezvous text at all
+
+
+def test_groups_of_launches_between_exchanges(lbm, monkeypatch):
+    """lbm_plan_group — what a partitioned run does between two halo exchanges (d2q9-bgk.c:326-328,364): the launches of
+    lbm_plan_steps for as long as their steps add up to at most the ghost rows (the first launch of a group advances the ghost
+    rows the later ones read).  K = 4 on 8 rows: two launches per exchange; rounds 1-3's loop is the case ghost = K."""
+    assert lbm.plan_groups(4, 8, 2, 20) == [[4, 4], [4, 4], [4]]
+    assert lbm.plan_groups(4, 8, 2, 21) == [[3, 3], [3, 4], [4, 4]]
+    assert lbm.plan_groups(4, 4, 1, 10) == [[3], [3], [4]] and lbm.plan_groups(4, 8, 1, 10) == [[3], [3], [4]]
+    assert lbm.plan_groups(4, 7, 2, 16) == [[4], [4], [4], [4]]                      # 4 + 4 > 7
+    assert lbm.plan_groups(4, 7, 2, 14) == [[3, 3], [4], [4]]
+    assert lbm.plan_groups(3, 8, 2, 20) == [[4, 4], [3, 3], [3, 3]]
+    assert lbm.plan_groups(4, 16, 4, 50) == [[3, 3, 4, 4], [4, 4, 4, 4], [4, 4, 4, 4], [4]]
+    assert lbm.plan_groups(2, 4, 2, 7) == [[2, 2], [2, 1]] and lbm.plan_groups(1, 2, 2, 3) == [[1, 1], [1]]
+    for K in (1, 2, 3, 4):
+        for ghost in range(K, 17):
+            for group in (1, 2, 3, 8):
+                for n in (1, 2, 5, 19, 20, 21, 22, 23, 64, 101):
+                    groups = lbm.plan_groups(K, ghost, group, n)
+                    flat = [k for g in groups for k in g]
+                    assert flat == lbm.plan_steps(K, n, four_rows=ghost >= 4)                      # the same launches, only grouped
+                    assert all(1 <= len(g) <= group and sum(g) <= ghost for g in groups)
+                    # greedy: a group ends only where the next launch would not fit (or the cap is reached, or the run ends)
+                    for g, nxt in zip(groups, groups[1:]):
+                        assert len(g) == group or sum(g) + nxt[0] > ghost
+    with pytest.raises(lbm.LbmError):
+        lbm.plan_groups(4, 3, 1, 10)                                                                # fewer ghost rows than a launch makes steps
+    # the layout's answer follows the environment knobs, identically on every rank
+    p = lbm.Params(8192, 8192, 10, 10, 0.1, 0.005, 1.85)
+    monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", "12")
+    assert [(l["ghost"], l["group"]) for l in (lbm.rank_layout(p, 8, r) for r in range(8))] == [(12, 3)] * 8
+    monkeypatch.setenv("LBM_TUNE_MACRO_GROUP", "2")
+    assert lbm.rank_layout(p, 8, 3)["group"] == 2
+    monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", "0")                                                 # rounds 1-3: K rows, one launch per exchange
+    monkeypatch.delenv("LBM_TUNE_MACRO_GROUP")
+    assert (lbm.rank_layout(p, 8, 3)["ghost"], lbm.rank_layout(p, 8, 3)["group"]) == (4, 1)
+    monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", "99")
+    assert lbm.rank_layout(p, 8, 3)["ghost"] == 16
