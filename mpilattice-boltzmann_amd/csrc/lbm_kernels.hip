@@ -551,17 +551,26 @@ static int macro_k_for(size_t max_cells)
 }
 
 // Ghost rows kept on each side of a K-step partition, and with them how often it exchanges: the launches between two exchanges (a
-// GROUP) make at most `ghost` steps together.  Round 4: 2 K rows, one exchange per TWO launches — the first launch of a group also
-// advances `ext` = (steps of the second) ghost rows on each side from the exchanged rows (under 1 % more cells at 1024 rows), so the
-// second is one launch over all tiles that reads no exchanged row: no interior / edge split, no push, no wait, no join.  Rounds 1-3 kept
-// K rows (4 at K = 3) and exchanged before every launch.  K = 3: 8 rows as well (3 + 4, 4 + 4, 3 + 3): step counts 3 does not divide
-// end in 3s and 4s, as lbm_run's.  LBM_TUNE_MACRO_GHOST overrides (0 or anything below K: K rows, one launch per exchange).
-// The exchange moves the rows the NEXT group needs (peer-to-peer loop) or all `ghost` rows (RCCL loop).
-static int macro_ghost_for(int k)
+// GROUP) make at most `ghost` steps together.  Round 4: the first launch of a group also advances `ext` = (steps of the later ones)
+// ghost rows on each side from the exchanged rows, so the later ones are launches over all tiles that read no exchanged row: no
+// interior / edge split, no push, no wait, no join.  Rounds 1-3 kept K rows (4 at K = 3) and exchanged before every launch.
+//   partitions that run the edge-stream schedule (>= 2 M cells): 2 K rows (8 at K = 3: 3 + 4, 4 + 4, 3 + 3), two launches per exchange —
+//     1-rank ring of 8192 x 1024 rows, us/step at 20 / 200 steps per run for K, 8, 12, 16 rows: 48.5 / 45.3, 46.5 / 43.7, 47.9 / 44.8, 49.0 / 45.1
+//     (12 rows: the first launch's 1040 rows are one tile row more than 1024 or 1032; profiles/r04/rings_p2p_first_build.txt);
+//   smaller ones (everything on one stream: each exchange is an exposed push + wait): as deep as their rows carry — 16 rows (four
+//     launches per exchange) from 128 rows per rank, 8 from 64, K below (a 32-row rank would compute 56 rows in a group's first launch) —
+//     1024 x 128 rows: 4.68 (K rows), 4.95 (8: the handshake before a push, which a group of launches needs, costs what one exchange
+//     saves), 4.37 (12), 4.13 (16) us/step at 200 steps, 6.65 / 6.46 / 6.26 / 5.96 at 20 (profiles/r04/rings_p2p_small.txt).
+// One answer for all ranks: from nx and the smallest / largest row count of the run.  LBM_TUNE_MACRO_GHOST overrides (0 or anything
+// below K: K rows, one launch per exchange).  The exchange moves the rows the NEXT group needs (peer-to-peer loop) or all `ghost`
+// rows (RCCL loop).
+static int macro_ghost_for(int k, int nx, int rows_min, int rows_max)
 {
   if (k <= 0) return 0;
-  const int by_k = k == 3 ? 8 : 2 * k;
-  return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_k), k), kMaxGhost);
+  const int classic = k == 3 ? 4 : k, two = k == 3 ? 8 : 2 * k;
+  int by_size = two;
+  if (static_cast<size_t>(nx) * rows_max < (size_t(1) << 21)) by_size = rows_min >= 128 ? std::max(16 / k * k, two) : rows_min >= 64 ? two : classic;
+  return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_size), k), kMaxGhost);
 }
 
 // Most launches per exchange: what the ghost rows allow (LBM_TUNE_MACRO_GROUP caps it; 1 = rounds 1-3's loop on any number of ghost rows).
@@ -679,7 +688,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->group_max = macro_group_for(forced_k, forced_ghost);
   } else if (forced_k < 0 && !self_periodic && obstacles_global && macro_eligible(p, ny_local, flags)) {
     const int k = macro_k_for(c->ncells);
-    if (k > 0) { c->multi_K = k; c->ghost = macro_ghost_for(k); c->group_max = macro_group_for(k, c->ghost); }
+    if (k > 0) { c->multi_K = k; c->ghost = macro_ghost_for(k, p->nx, ny_local, ny_local); c->group_max = macro_group_for(k, c->ghost); }
   }
   c->multi_tail4 = tune_env("LBM_TUNE_MULTI_TAIL4", 1) != 0;
   c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
@@ -873,7 +882,7 @@ int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, l
   const bool partitioned = nranks > 1 || (flags & LBM_FLAG_FORCE_HALO);
   if (partitioned && macro_eligible(p, lo, flags) && macro_eligible(p, hi, flags))
     out->macro_k = macro_k_for(static_cast<size_t>(p->nx) * hi);
-  out->ghost = macro_ghost_for(out->macro_k);
+  out->ghost = macro_ghost_for(out->macro_k, p->nx, lo, hi);
   out->group = macro_group_for(out->macro_k, out->ghost);
   return 0;
 }

@@ -71,7 +71,7 @@ struct lbm_p2p {
   size_t window_bytes = 0, reduce_cap = 0, halo_bytes = 0;   // halo_bytes: one-step mode's incoming messages, [2 parities][2 dirs][3 * nxp] floats
   const char* window_kind = "coarse";
   int* err = nullptr;                  // host-mapped error word written by the wait kernels
-  unsigned int* done = nullptr;        // block-done counter of the push kernel
+  unsigned int* done = nullptr;        // block-done counter of the push kernel, and behind it (at +2) the 64-bit "go" word of its handshake
   double* reduce_out = nullptr;        // folded global sums of one reduce round (host-mapped: the fold kernel writes, the host reads)
   double** d_slots = nullptr;          // device arrays of per-rank pointers, [2 parities][nranks]
   unsigned long long** d_flags = nullptr;
@@ -147,7 +147,9 @@ double p2p_avg_us(const std::vector<P2PSpan>& v, size_t from = 0)
 // The k rows of the CURRENT grid that each neighbour needs for its next group of launches (k steps in all), into the k ghost rows
 // next to its owned rows in the grid of the same parity — once both neighbours have said that they are done with the rows of the
 // epoch before — flags := epoch; then (same kernel) wait for the neighbours' rows of that epoch to have arrived here.
-int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool exposed = false)
+// handshake: the launches since the previous exchange were more than one (see P2PWindowHeader::halo_ack); never needed for the first
+// push of a run — every rank's launches of the run before are complete when any rank leaves its reduction.
+int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool handshake, bool exposed = false)
 {
   lbm_ctx* c = t->ctx;
   const P2PPeer& ps = t->peers[t->south];
@@ -172,18 +174,21 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
   a.epoch = epoch;
   a.parity = static_cast<unsigned long long>(g);
   a.done = t->done;
+  a.go = reinterpret_cast<unsigned long long*>(t->done + 2);
   a.wait_flags = header_of(t->window)->halo_flag;
   a.wait_parity = header_of(t->window)->halo_parity;
   a.ack[0] = &header_of(ps.window)->halo_ack[1];         // I am the south neighbour's NORTH neighbour
   a.ack[1] = &header_of(pn.window)->halo_ack[0];
-  a.wait_ack = header_of(t->window)->halo_ack;
+  a.wait_ack = handshake ? header_of(t->window)->halo_ack : nullptr;
   a.timeout_ticks = t->timeout_ticks;
   a.err = t->err;
   const int work = 18 * (a.nfloats / 2);
   // at most 64 blocks (every block ends with an L2 write-back towards the peers), each lane moving up to four
   // float2's per pass
   // (`exposed`: the push before the first macro-step of a run in the serial schedule, which nothing overlaps)
-  const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge : kP2PPushBlocks;
+  // (pushes of more than four rows, round 4: twice the blocks — 8 rows beside the interior launch of 8192 x 1024 rows, us/step at 20 / 200
+  // steps per run for 16 / 32 / 64 / 128 blocks: 51.9 / 49.4, 46.9 / 43.5, 47.0 / 43.1, 48.6 / 44.0; profiles/r04/ring_push_blocks.txt)
+  const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge * (k > 4 ? 2 : 1) : kP2PPushBlocks;
   const dim3 grid(std::max(1, std::min(max_blocks, (work + 1023) / 1024)));
   hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
   HIP_TRY(hipGetLastError());
@@ -359,8 +364,8 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   P2P_TRY(hipMemset(t->window, 0, t->window_bytes));
   P2P_TRY(hipHostMalloc(reinterpret_cast<void**>(&t->err), sizeof(int), hipHostMallocMapped));
   *t->err = 0;
-  P2P_TRY(hipMalloc(&t->done, sizeof(unsigned int)));
-  P2P_TRY(hipMemset(t->done, 0, sizeof(unsigned int)));
+  P2P_TRY(hipMalloc(&t->done, 4 * sizeof(unsigned int)));
+  P2P_TRY(hipMemset(t->done, 0, 4 * sizeof(unsigned int)));
   P2P_TRY(hipHostMalloc(reinterpret_cast<void**>(&t->reduce_out), sizeof(double) * t->reduce_cap, hipHostMallocMapped));
   P2P_TRY(hipMalloc(&t->d_slots, sizeof(double*) * 2 * nranks));
   P2P_TRY(hipMalloc(&t->d_flags, sizeof(unsigned long long*) * nranks));
@@ -573,11 +578,11 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));       // "the accelerated state is ready"
       P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
       sp.begin = p2p_stamp(t, es);
-      if (p2p_push(t, epoch, g.total, es)) return bail();
+      if (p2p_push(t, epoch, g.total, es, /*handshake=*/false)) return bail();
       sp.end = p2p_stamp(t, es);
     } else {
       sp.begin = p2p_stamp(t, cs);
-      if (p2p_push(t, epoch, g.total, cs, /*exposed=*/true)) return bail();
+      if (p2p_push(t, epoch, g.total, cs, /*handshake=*/false, /*exposed=*/true)) return bail();
       sp.end = p2p_stamp(t, cs);
     }
     if (t->profile) sp_push.push_back(sp);
@@ -647,7 +652,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       }
       P2PSpan sp;
       sp.begin = p2p_stamp(t, es);
-      if (p2p_push(t, epoch + 1, next.total, es)) return bail();
+      if (p2p_push(t, epoch + 1, next.total, es, /*handshake=*/g.n > 1)) return bail();
       sp.end = p2p_stamp(t, es);
       if (t->profile) sp_push.push_back(sp);
       g = next;

@@ -7,6 +7,8 @@
 #   rings[:<grids>]               1-rank peer-to-peer rings, ONE PER PROCESS, over the halo depths (LBM_TUNE_MACRO_GHOST) 0 8 12 16 at
 #                                 20 and 200 steps per run — a rank's share of a partitioned run, the wire a self-copy (default grids: 8192x1024 1024x128)
 #   ringsrccl[:<grids>]           the same over the RCCL loop
+#   ring1:<grid>:<steps>:<rounds>:<VAR=val VAR=val ...>   one ring in one process under that environment (wall time per run, as bench.py times it)
+#   ringbench:<grid>[:<steps>]    bench.py --ring on one grid (default 20 steps): the line with `phases` in ring_<grid>_s<steps>.json
 #   bench[:<bench.py args>]       bench.py (default: the driver's --steps 20 --warmup 5), the line in bench.json
 #   prof[:<bench.py args>]        rocprofv3 --kernel-trace --stats of bench.py, summary in prof/
 #   pmc:<counters>:<bench args>   one rocprofv3 --pmc pass of bench.py (its own run, no trace flags)
@@ -45,6 +47,20 @@ step() {
     smoke) timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee "$OUT/smoke.log" ;;
     rings) ring_lines p2p "$OUT/rings_p2p.txt" ${arg:-8192x1024 1024x128} ;;
     ringsrccl) ring_lines rccl "$OUT/rings_rccl.txt" ${arg:-8192x1024 1024x128} ;;
+    ring1)
+      local g st ro ev; IFS=: read -r g st ro ev <<< "$arg"
+      echo "== ring $g, $st steps per run, env: $ev" | tee -a "$OUT/ring1.txt"
+      env $ev timeout -k 10 240 python scripts/ab_ring.py --grid $g --steps $st --rounds $ro - 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a "$OUT/ring1.txt" ;;
+    ringbench)
+      local g=${arg%%:*} st=20; [ "$g" != "$arg" ] && st=${arg#*:}
+      timeout -k 10 300 python bench.py --ring --workload $g --steps $st --warmup 5 --no-cpu-baseline --no-variants --no-secondary > "$OUT/ring_${g}_s$st.json" 2> "$OUT/ring_${g}_s$st.err"
+      local rc=$?; python - "$OUT/ring_${g}_s$st.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+ph = d.get("phases", {}).get("max_over_ranks", {})
+print(f"ring {d['config'].get('workload')}: {d['ms_per_step'] * 1e3:.2f} us/step; " + ", ".join(f"{k} {v:.1f}" for k, v in ph.items()))
+PY
+      return $rc ;;
     bench) timeout -k 10 500 python bench.py ${arg:---steps 20 --warmup 5} > "$OUT/bench.json" 2> "$OUT/bench.err"; local rc=$?; tail -c 1500 "$OUT/bench.json"; return $rc ;;
     prof)
       rm -rf "$OUT/prof"

@@ -944,8 +944,10 @@ def test_groups_of_launches_per_exchange_on_a_ring_of_one(lbm, oracle, monkeypat
     obst = lbm.synthetic_obstacles(nx, ny, 0.03, nx * 5 + ny, False)
     sim = lbm.Simulation(p, obst, flags=lbm._capi.FLAG_FORCE_HALO, exchange=exchange, strict=True)
     lay = sim.layout
-    want_ghost = max(min(int(ghost), 16), K) if ghost else (8 if K == 3 else 2 * K)
-    assert sim.loop == exchange and (lay["macro_k"], lay["ghost"]) == (K, want_ghost) and lay["group"] == (int(group) if group else max(want_ghost // K, 1))
+    two = 8 if K == 3 else 2 * K                         # the default: by the rank's size (lbm_kernels.hip macro_ghost_for)
+    by_size = two if nx * ny >= 1 << 21 else max(16 // K * K, two) if ny >= 128 else two if ny >= 64 else (4 if K == 3 else K)
+    want_ghost = max(min(int(ghost), 16), K) if ghost else by_size
+    assert sim.loop == exchange and (lay["macro_k"], lay["ghost"]) == (K, want_ghost) and lay["group"] == (int(group) if group else min(max(want_ghost // K, 1), 8))
     av = np.concatenate([sim.run(n) for n in runs])
     cells = sim.local_cells()
     sim.close()

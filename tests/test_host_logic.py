@@ -160,14 +160,17 @@ def test_rank_layout_is_one_decision_for_all_ranks(lbm):
     (ny = 190 on 6 ranks: 32,32,32,32,31,31; ny = 127 on 4: 32,32,32,31) and partitions straddling the
     K = 3 / K = 4 size threshold give every rank the same answer."""
     for nx, ny, size in [(1024, 190, 6), (1024, 127, 4), (8192, 8192, 8), (1024, 1024, 8), (2048, 2049, 2), (8192, 515, 2),
-                         (130, 100, 3), (126, 400, 4), (8192, 8192, 1), (4096, 1000, 7)]:
+                         (130, 100, 3), (126, 400, 4), (8192, 8192, 1), (4096, 1000, 7), (1024, 1024, 16), (256, 200, 2)]:
         p = lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
         lays = [lbm.rank_layout(p, size, r) for r in range(size)]
         nyl, dis = lbm.decompose(ny, size)
         assert [l["ny_local"] for l in lays] == nyl and [l["y0"] for l in lays] == dis
         assert len({l["macro_k"] for l in lays}) == 1, lays
-        # 2 K ghost rows, two launches per halo exchange (round 4); nothing to keep in one-step mode
-        assert all((l["ghost"], l["group"]) == ((8, 2) if l["macro_k"] == 4 else (0, 1)) for l in lays)
+        # ghost rows and launches per halo exchange (round 4), one answer for all ranks: 2 K rows, two launches for ranks of >= 2 M cells
+        # (the edge-stream schedule); below, as deep as the rows carry: 16 rows, four launches from 128 rows per rank, 8 from 64, else K
+        big = nx * max(nyl) >= 1 << 21
+        want = (0, 1) if lays[0]["macro_k"] == 0 else (8, 2) if big or 64 <= min(nyl) < 128 else (16, 4) if min(nyl) >= 128 else (4, 1)
+        assert all((l["ghost"], l["group"]) == want for l in lays), (nx, ny, size, lays)
         k = lays[0]["macro_k"]
         if size == 1:
             assert k == 0                                            # a whole periodic grid needs no ghost rows ...
