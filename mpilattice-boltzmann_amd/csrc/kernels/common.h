@@ -156,6 +156,32 @@ __device__ __forceinline__ void lds_barrier()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// ---- bounded waits on flag words of a rank's exported window (peer-to-peer loop, kernels/p2p.h; the fold block of lbm_multi_kernel) ----
+// Polls are RELAXED system-scope loads of the uncached window (an acquire load per poll would invalidate this XCD's
+// caches on every iteration, under the feet of the launch running beside it); ONE acquire fence follows the last
+// of them.  What the flags guard is read by a later kernel of the stream in any case.
+// acquire = false: nothing the flags guard is READ afterwards (the "ready" words, which only hold back this rank's stores).
+__device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, const unsigned long long* parity_words, int nflags, unsigned long long epoch,
+                                               unsigned long long parity, long long timeout_ticks, int* err, bool acquire = true)
+{
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  const long long t0 = wall_clock64();
+  for (int f = 0; f < nflags; ++f) {
+    while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(err, 1 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);                             // ~128 cycles between polls: the flag is a remote write away
+    }
+    if (parity_words && __hip_atomic_load(parity_words + 2 * f + (epoch & 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
+      __hip_atomic_store(err, 100 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+  if (acquire) __atomic_thread_fence(__ATOMIC_ACQUIRE);        // system scope
+}
+
 // Deterministic block sum (fixed tree): every thread gets the total.
 __device__ __forceinline__ double block_sum(double v, double* lds /* kBlock/64 doubles */)
 {

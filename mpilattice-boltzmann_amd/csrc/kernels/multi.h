@@ -118,6 +118,17 @@ struct MultiArgs {
   int n_prev, n_prev_vecs;
   double* sums;
   int* counter;
+  // peer-to-peer loop, the LAST launch of a group of several: "ready for epoch `ready_epoch`" to both neighbours (kernels/p2p.h
+  // P2PWindowHeader::halo_ack), said by the fold block as the launch starts — this launch reads ghost rows of its source grid only and
+  // writes owned rows, so the ghost rows of its destination grid, the next push's target, are free from here on.  0: nothing to say.
+  unsigned long long* ready[2];
+  unsigned long long ready_epoch;
+  // ... and, once the fold is done, waits until both neighbours have said the same to this rank (bounded; err is the transport's
+  // host-mapped error word): the push kernel that follows this launch in the stream then stores without asking.  Every rank speaks
+  // before it waits, so a ring of ranks cannot dead-lock here; the wait overlaps the launch's own tiles.
+  const unsigned long long* wait_ready;  // this rank's halo_ack[2], or null
+  long long timeout_ticks;
+  int* err;
 };
 
 // A pair (x, x+1), x even, of population k into row `row` (a dword index) of an LDS frame of row stride W: interleaved
@@ -150,6 +161,9 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int tid = threadIdx.x;
 
   if (blockIdx.x == 0) {
+    if (a.ready_epoch != 0ull && tid == 0) {
+      for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
     for (int v = 0; v < a.n_prev_vecs; ++v) {
       double s = 0.0;
@@ -166,6 +180,7 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     }
     __syncthreads();
     if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
+    if (a.wait_ready && tid == 0) p2p_wait_flags(a.wait_ready, nullptr, 2, a.ready_epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
     return;
   }
 

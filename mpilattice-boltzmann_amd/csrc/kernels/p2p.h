@@ -17,8 +17,8 @@ struct P2PWindowHeader {                 // start of every rank's exported windo
   unsigned long long halo_parity[4];     // [2*dir + (epoch & 1)]: the pusher's grid parity for that epoch (lock-step check).  A pusher
                                          // may run ONE epoch ahead of the waiter, never two: a slot per epoch parity is not overwritten early
   unsigned long long reduce_flag[64];    // [r]: rank r's sums of reduce round N are in my slot r
-  unsigned long long halo_ack[2];        // [0]: my SOUTH neighbour has finished every launch that reads or writes its ghost rows of the epochs before
-                                         // this one and is about to push: its ghost rows may be written for this epoch; [1]: NORTH.  The two grids
+  unsigned long long halo_ack[2];        // [0]: my SOUTH neighbour has finished every launch that reads or writes its ghost rows of the grid the push of
+                                         // this epoch writes: they may be written; [1]: NORTH.  The two grids
                                          // double-buffered the ghost rows only as long as every exchange was followed by ONE launch (rounds 1-3): a
                                          // group of two launches returns to the grid it started from, and the rows of epoch e+1 would land in the
                                          // rows a neighbour still reads for epoch e.
@@ -37,42 +37,14 @@ struct P2PPushArgs {
   unsigned long long* parity_word[2];
   unsigned long long epoch, parity;
   unsigned int* done;                    // block-done counter (my device memory), zero between launches
-  unsigned long long* go;                // the epoch whose handshake block 0 has completed (my device memory)
   // then wait (block 0, one lane) until BOTH neighbours' rows of the same epoch have arrived here: the push of a
   // macro-step and the wait before the next one are always adjacent in the stream, and one kernel boundary less
   // per macro-step is what a 1024 x 128-row partition notices (20 % of its step)
   const unsigned long long* wait_flags;  // my halo_flag[2], or null: push only
   const unsigned long long* wait_parity; // my halo_parity[4]
-  unsigned long long* ack[2];            // [0]: the south neighbour's halo_ack[1] (I am ITS north neighbour); [1]: the north neighbour's halo_ack[0]
-  const unsigned long long* wait_ack;    // my halo_ack[2]; null: no handshake (the launches since the last exchange were ONE: the two grids are the double buffer)
   long long timeout_ticks;
   int* err;
 };
-
-// Polls are RELAXED system-scope loads of the uncached window (an acquire load per poll would invalidate this XCD's
-// caches on every iteration, under the feet of the launch running beside it); ONE acquire fence follows the last
-// of them.  What the flags guard is read by a later kernel of the stream in any case.
-// acquire = false: nothing the flags guard is READ afterwards (the "ready" words, which only hold back this rank's stores).
-__device__ __forceinline__ void p2p_wait_flags(const unsigned long long* flags, const unsigned long long* parity_words, int nflags, unsigned long long epoch,
-                                               unsigned long long parity, long long timeout_ticks, int* err, bool acquire = true)
-{
-  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
-  const long long t0 = wall_clock64();
-  for (int f = 0; f < nflags; ++f) {
-    while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      if (wall_clock64() - t0 > timeout_ticks) {
-        __hip_atomic_store(err, 1 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(2);                             // ~128 cycles between polls: the flag is a remote write away
-    }
-    if (parity_words && __hip_atomic_load(parity_words + 2 * f + (epoch & 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != parity) {
-      __hip_atomic_store(err, 100 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-  }
-  if (acquire) __atomic_thread_fence(__ATOMIC_ACQUIRE);        // system scope
-}
 
 // My first K owned rows -> the south neighbour's top ghost rows, my last K owned rows -> the north
 // neighbour's bottom ghost rows (all 9 planes), then the two epoch flags, raised by the last block to
@@ -84,30 +56,10 @@ constexpr int kP2PPushBlocks = 64;
 
 __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, int nx)
 {
-  // "Ready for epoch e" (only where the launches since the last exchange were more than one: a.wait_ack != null): this kernel
-  // follows, in its stream, every launch of mine that touches my ghost rows of the earlier epochs.  Block 0 — the first block
-  // dispatched, which waits for nobody of its own launch — says so to both neighbours, waits until both have said it to me, and then
-  // lets the other blocks go through a word in device memory (agent scope).  One poller of the uncached window, as for the data flags:
-  // with every block storing and polling the same two uncached words a push took 23 us instead of 7 on a 1024 x 128-row ring.
-  // Nobody waits before its block 0 has spoken, so a ring of ranks cannot dead-lock here; a time-out releases the other blocks too.
-  __shared__ int go;
-  if (threadIdx.x == 0) {
-    go = 1;
-    if (a.wait_ack) {
-      if (blockIdx.x == 0) {
-        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ack[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        p2p_wait_flags(a.wait_ack, nullptr, 2, a.epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
-        __hip_atomic_store(a.go, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        while (__hip_atomic_load(a.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch) __builtin_amdgcn_s_sleep(1);   // bounded by block 0's wait
-      }
-      go = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
-    }
-  }
-  __syncthreads();
-  const bool ok = go != 0;                                     // a neighbour never got here: store nothing into its rows, raise nothing
+  // (Where the launches since the last exchange were more than one, both neighbours have said that their ghost rows may be written
+  // before this kernel starts: the fold block of this rank's last launch waited for it, MultiArgs::wait_ready.)
   const int per_plane = a.nfloats / 2;                         // float2's of one plane's rows (nx even)
-  const int total = ok ? per_plane * 18 : 0;
+  const int total = per_plane * 18;
   // four independent loads in flight per lane, then their stores: the kernel is a chain of memory round trips
   // (a 1024 x 4-row message is 295 KB: one pass), not a bandwidth problem
   constexpr int kUnroll = 4;
@@ -139,7 +91,7 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
     const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == gridDim.x - 1) {                               // the last block raises the flags
       __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ok && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {   // (a block that timed out stored nothing)
+      if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {   // (after a time-out the run is failing: raise nothing)
         for (int d = 0; d < 2; ++d) __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __builtin_amdgcn_s_waitcnt(0);                         // parity words before flags (both write-through)
         for (int d = 0; d < 2; ++d) __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -108,6 +108,11 @@ struct lbm_ctx {
   int accel_row = -1;
   int ghost = 0;             // storage rows below / above the owned rows (K-step kernels of a row-partitioned run)
   int group_max = 1;         // most launches a partitioned run makes per halo exchange (a group: their steps add up to <= ghost)
+  unsigned long long* ready_ptr[2] = {nullptr, nullptr};   // peer-to-peer loop: the next launch_multi says "ready for epoch ready_epoch" to the
+  unsigned long long ready_epoch = 0;                       // neighbours (MultiArgs::ready) and waits for theirs; cleared by that launch
+  const unsigned long long* ready_wait = nullptr;
+  long long ready_timeout_ticks = 0;
+  int* ready_err = nullptr;
   bool nt_stores = false;
   bool fast_avvels = false;  // LBM_FLAG_FAST_AVVELS: float sum|u| terms in lbm_multi_kernel / lbm_tile_kernel
   int multi_terms = kTermsCompensated;   // lbm_multi_kernel's form of the terms (kernels/common.h): LBM_FLAG_FAST_AVVELS / LBM_FLAG_EXACT_AVVELS
@@ -338,6 +343,9 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.prev_partials = c->partials[c->parity ^ 1];
   a.n_prev = fold ? c->n_prev : 0; a.n_prev_vecs = (fold && c->n_prev > 0) ? c->n_prev_vecs : 0;
   a.sums = c->sums; a.counter = c->counter;
+  a.ready[0] = c->ready_ptr[0]; a.ready[1] = c->ready_ptr[1]; a.ready_epoch = c->ready_epoch;
+  a.wait_ready = c->ready_epoch ? c->ready_wait : nullptr; a.timeout_ticks = c->ready_timeout_ticks; a.err = c->ready_err;
+  c->ready_epoch = 0;
   const int blocks = n0 + n1;
   // measured on 8192x8192, K=2: 515 us/step with the XCD-contiguous tile order, 549 without
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
@@ -559,8 +567,9 @@ static int macro_k_for(size_t max_cells)
 //     (12 rows: the first launch's 1040 rows are one tile row more than 1024 or 1032; profiles/r04/rings_p2p_first_build.txt);
 //   smaller ones (everything on one stream: each exchange is an exposed push + wait): as deep as their rows carry — 16 rows (four
 //     launches per exchange) from 128 rows per rank, 8 from 64, K below (a 32-row rank would compute 56 rows in a group's first launch) —
-//     1024 x 128 rows: 4.68 (K rows), 4.95 (8: the handshake before a push, which a group of launches needs, costs what one exchange
-//     saves), 4.37 (12), 4.13 (16) us/step at 200 steps, 6.65 / 6.46 / 6.26 / 5.96 at 20 (profiles/r04/rings_p2p_small.txt).
+//     1024 x 128 rows: 4.85 (K rows), 4.23 (8), 3.85 (12), 3.84 (16) us/step at 200 steps, 6.40 / 6.12 / 5.87 / 5.65 at 20
+//     (profiles/r04/rings_p2p_small.txt; with the neighbours' "ready" awaited inside the push kernel, by every block or by block 0 with a
+//     go word for the rest, 8 rows were no faster than K: 4.95 - 5.76 — the wait now sits in the fold block of the group's last launch).
 // One answer for all ranks: from nx and the smallest / largest row count of the run.  LBM_TUNE_MACRO_GHOST overrides (0 or anything
 // below K: K rows, one launch per exchange).  The exchange moves the rows the NEXT group needs (peer-to-peer loop) or all `ghost`
 // rows (RCCL loop).

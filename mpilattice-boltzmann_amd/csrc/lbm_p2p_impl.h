@@ -71,7 +71,7 @@ struct lbm_p2p {
   size_t window_bytes = 0, reduce_cap = 0, halo_bytes = 0;   // halo_bytes: one-step mode's incoming messages, [2 parities][2 dirs][3 * nxp] floats
   const char* window_kind = "coarse";
   int* err = nullptr;                  // host-mapped error word written by the wait kernels
-  unsigned int* done = nullptr;        // block-done counter of the push kernel, and behind it (at +2) the 64-bit "go" word of its handshake
+  unsigned int* done = nullptr;        // block-done counter of the push kernel
   double* reduce_out = nullptr;        // folded global sums of one reduce round (host-mapped: the fold kernel writes, the host reads)
   double** d_slots = nullptr;          // device arrays of per-rank pointers, [2 parities][nranks]
   unsigned long long** d_flags = nullptr;
@@ -147,9 +147,23 @@ double p2p_avg_us(const std::vector<P2PSpan>& v, size_t from = 0)
 // The k rows of the CURRENT grid that each neighbour needs for its next group of launches (k steps in all), into the k ghost rows
 // next to its owned rows in the grid of the same parity — once both neighbours have said that they are done with the rows of the
 // epoch before — flags := epoch; then (same kernel) wait for the neighbours' rows of that epoch to have arrived here.
-// handshake: the launches since the previous exchange were more than one (see P2PWindowHeader::halo_ack); never needed for the first
-// push of a run — every rank's launches of the run before are complete when any rank leaves its reduction.
-int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool handshake, bool exposed = false)
+// The next launch of this rank's context — the last of a group of several — tells both neighbours that this rank's ghost rows may be
+// written for `epoch` (MultiArgs::ready): I am the south neighbour's NORTH neighbour and the north neighbour's SOUTH one.
+void p2p_say_ready(lbm_p2p* t, unsigned long long epoch)
+{
+  lbm_ctx* c = t->ctx;
+  c->ready_ptr[0] = &header_of(t->peers[t->south].window)->halo_ack[1];
+  c->ready_ptr[1] = &header_of(t->peers[t->north].window)->halo_ack[0];
+  c->ready_epoch = epoch;
+  c->ready_wait = header_of(t->window)->halo_ack;
+  c->ready_timeout_ticks = t->timeout_ticks;
+  c->ready_err = t->err;
+}
+
+// (After a group of SEVERAL launches the push needs the neighbours' word that their ghost rows may be written — see
+// P2PWindowHeader::halo_ack; it is said and awaited by the group's last launch, p2p_say_ready.  Never needed for the first push of a
+// run: every rank's launches of the run before are complete when any rank leaves its reduction.)
+int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool exposed = false)
 {
   lbm_ctx* c = t->ctx;
   const P2PPeer& ps = t->peers[t->south];
@@ -174,12 +188,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ha
   a.epoch = epoch;
   a.parity = static_cast<unsigned long long>(g);
   a.done = t->done;
-  a.go = reinterpret_cast<unsigned long long*>(t->done + 2);
   a.wait_flags = header_of(t->window)->halo_flag;
   a.wait_parity = header_of(t->window)->halo_parity;
-  a.ack[0] = &header_of(ps.window)->halo_ack[1];         // I am the south neighbour's NORTH neighbour
-  a.ack[1] = &header_of(pn.window)->halo_ack[0];
-  a.wait_ack = handshake ? header_of(t->window)->halo_ack : nullptr;
   a.timeout_ticks = t->timeout_ticks;
   a.err = t->err;
   const int work = 18 * (a.nfloats / 2);
@@ -578,11 +588,11 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       P2P_RUN_TRY(hipEventRecord(t->interior_done, cs));       // "the accelerated state is ready"
       P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0));
       sp.begin = p2p_stamp(t, es);
-      if (p2p_push(t, epoch, g.total, es, /*handshake=*/false)) return bail();
+      if (p2p_push(t, epoch, g.total, es)) return bail();
       sp.end = p2p_stamp(t, es);
     } else {
       sp.begin = p2p_stamp(t, cs);
-      if (p2p_push(t, epoch, g.total, cs, /*handshake=*/false, /*exposed=*/true)) return bail();
+      if (p2p_push(t, epoch, g.total, cs, /*exposed=*/true)) return bail();
       sp.end = p2p_stamp(t, cs);
     }
     if (t->profile) sp_push.push_back(sp);
@@ -617,6 +627,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       group_launch_done(c, g, 0, 2);
       for (int i = 1; i < g.n; ++i) {                          // over all tiles: nothing exchanged is read
         if (i == 1) P2P_RUN_TRY(hipStreamWaitEvent(cs, t->edge_done, 0));
+        if (i == g.n - 1 && more) p2p_say_ready(t, epoch + 1);
         P2PSpan sw;
         sw.begin = p2p_stamp(t, cs);
         launch_group_whole(c, g, i, more, cs);
@@ -629,6 +640,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       es_has_waited = false;
     } else {
       for (int i = 0; i < g.n; ++i) {
+        if (g.n > 1 && i == g.n - 1 && more) p2p_say_ready(t, epoch + 1);
         P2PSpan sp;
         sp.begin = p2p_stamp(t, cs);
         launch_group_whole(c, g, i, more, cs);
@@ -652,7 +664,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       }
       P2PSpan sp;
       sp.begin = p2p_stamp(t, es);
-      if (p2p_push(t, epoch + 1, next.total, es, /*handshake=*/g.n > 1)) return bail();
+      if (p2p_push(t, epoch + 1, next.total, es)) return bail();
       sp.end = p2p_stamp(t, es);
       if (t->profile) sp_push.push_back(sp);
       g = next;

@@ -50,7 +50,7 @@ step() {
     ring1)
       local g st ro ev; IFS=: read -r g st ro ev <<< "$arg"
       echo "== ring $g, $st steps per run, env: $ev" | tee -a "$OUT/ring1.txt"
-      env $ev timeout -k 10 240 python scripts/ab_ring.py --grid $g --steps $st --rounds $ro - 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a "$OUT/ring1.txt" ;;
+      env ${ev//@/ } timeout -k 10 240 python scripts/ab_ring.py --grid $g --steps $st --rounds $ro - 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a "$OUT/ring1.txt" ;;
     ringbench)
       local g=${arg%%:*} st=20; [ "$g" != "$arg" ] && st=${arg#*:}
       timeout -k 10 300 python bench.py --ring --workload $g --steps $st --warmup 5 --no-cpu-baseline --no-variants --no-secondary > "$OUT/ring_${g}_s$st.json" 2> "$OUT/ring_${g}_s$st.err"
