@@ -32,6 +32,9 @@ namespace {
 #ifndef LBM_MTY4           // tile height of the 4-step instantiation, standard and narrow geometry (512 lanes)
 #define LBM_MTY4 13
 #endif
+#ifndef LBM_LDS_ROWMAP     // in-LDS sub-steps: rows dealt to aligned 32-lane groups (1) or lane t -> row t / wp (0: the default).  Round 4, measured:
+#define LBM_LDS_ROWMAP 0   // 1 takes SQ_LDS_BANK_CONFLICT from 90.5 M to 29.0 M cycles per launch (LDS active 240 M -> 179 M) and moves the time by
+#endif                     // nothing: 8192 x 8192 300.4 -> 301.4 us/step, 4096 x 4096 77.4 -> 77.6, 512 x 512 3.16 -> 3.22 (profiles/r04/ab_lds_rowmap.txt)
 #ifndef LBM_MTY4T          // tile height and block size of the 4-step instantiation, tall geometry
 #define LBM_MTY4T 23
 #define LBM_MLANES4T 768
@@ -314,19 +317,38 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     // frame it read kept row r-1 (the frame creeps down one storage row per sub-step), and a region
     // of more than 512 pairs goes in passes of whole rows, bottom to top.  A pass reads, meets at a
     // barrier, then writes; what it overwrites (old rows up to its last row - 1) no later pass reads.
-    auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
-      const int ey = ksteps - j, ex = 2 * ey;
-      const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
-      const int rows = TY + 2 * ey;
-      const int rpp = kLanes / wp;                                       // whole rows per pass
-      const bool last = j == ksteps;
+    auto in_lds_substep = [&](auto j_const) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_const)::value;                        // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
+      constexpr int ey = ksteps - j, ex = 2 * ey;
+      constexpr int wp = (TX + 2 * ex) / 2;                            // pairs per region row
+      constexpr int rows = TY + 2 * ey;
+      constexpr int rpp = kLanes / wp;                                   // whole rows per pass
+      constexpr bool last = j == ksteps;
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
-      const int ry = tid / wp, rp = tid - ry * wp;
-      const int fx = EX - ex + 2 * rp;
+      // Lanes to pairs of a pass (LBM_LDS_ROWMAP = 1: an experiment, bit-exact, no faster — the launch is not LDS-bound).  LDS reads are served in 32-lane groups, one cycle per group unless two lanes of a group meet on a
+      // bank at different addresses: with the pairs of a pass dealt row after row (lane t -> row t / wp) almost every group straddles two
+      // region rows, whose addresses are W - wp (split planes) or W - 2 wp (interleaved ones) dwords apart beyond the lane step — 8 / 4
+      // banks at wp = 36: a two-way conflict in nine groups of ten, 38 % of all LDS cycles (SQ_LDS_BANK_CONFLICT, profiles/r03).  So the
+      // first 32 pairs of every row go to one ALIGNED group of 32 lanes (consecutive dwords: no conflict on either kind of plane), and
+      // the wp - 32 = 4 or 2 pairs left over per row are gathered into the last groups of the pass.
+      // (The leftover groups follow the aligned groups of THE PASS'S OWN rows: behind those of a full pass, the few lanes of a short second
+      // pass would wake a wave of their own — 61 wave-passes per tile instead of 60, which measured +2 % at every size.)
+      constexpr int tailw = LBM_LDS_ROWMAP && wp > 32 && (wp - 32 == 4 || wp - 32 == 2) ? wp - 32 : 0;
+#pragma unroll
       for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count: unrolled)
+        const int nr = rows - r0 < rpp ? rows - r0 : rpp;                // rows of this pass (a constant once unrolled)
+        int ry, rp;
+        if constexpr (tailw > 0) {
+          const int u = tid - nr * 32;                                   // < 0: one of the aligned groups
+          ry = u < 0 ? (tid >> 5) : u / tailw;                           // (lanes past the pass's pairs: ry >= nr, idle below)
+          rp = u < 0 ? (tid & 31) : 32 + (u & (tailw - 1));
+        } else {
+          ry = tid / wp; rp = tid - ry * wp;
+        }
+        const int fx = EX - ex + 2 * rp;
         f2 outs[9];
         int slot = -1;
-        const bool in_region = ry < rpp && r0 + ry < rows;
+        const bool in_region = ry < nr;
         // whole waves without work skip the pass; in the others every lane computes (an idle lane on the
         // region's first row) and only the write is predicated: no per-lane state to merge at the barrier
         if (__builtin_amdgcn_ballot_w64(in_region) != 0ull) {
@@ -377,9 +399,10 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
       if (!last) __syncthreads();
       LBM_MSTAMP(1 + j);
     };
-    // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
-#pragma unroll
-    for (int j = 2; j <= K; ++j) in_lds_substep(j);
+    if constexpr (K >= 2) in_lds_substep(std::integral_constant<int, 2>{});
+    if constexpr (K >= 3) in_lds_substep(std::integral_constant<int, 3>{});
+    if constexpr (K >= 4) in_lds_substep(std::integral_constant<int, 4>{});
+    static_assert(K <= 4, "sub-steps 2 .. K are spelled out");
   }
 
   // per-step sums over the owned cells of this tile

@@ -12,6 +12,8 @@
 #   bench[:<bench.py args>]       bench.py (default: the driver's --steps 20 --warmup 5), the line in bench.json
 #   prof[:<bench.py args>]        rocprofv3 --kernel-trace --stats of bench.py, summary in prof/
 #   pmc:<counters>:<bench args>   one rocprofv3 --pmc pass of bench.py (its own run, no trace flags)
+#   pmcsum:<counters>[:<tag>]     the same, then the mean per launch of every counter for lbm_multi_kernel<4 (appended to pmcsum.txt)
+#   uselib:<variant>              ON THE BOX: lib/variants/<variant>.so takes the place of lib/liblbm_d2q9.so for the steps that follow
 #   decks                         the four shipped decks through bin/d2q9-bgk
 #   fuzz[:<cases>]                scripts/fuzz_kernels.py
 #   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
@@ -71,6 +73,21 @@ PY
       local d="$OUT/pmc_$(echo $ctr | tr ' ' '_' | cut -c1-40)"; rm -rf "$d"
       timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py ${rest:---steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-phases --no-power} > "$d.json" 2> "$d.err"
       local rc=$?; tail -3 "$d.err"; return $rc ;;
+    pmcsum)
+      local ctr=${arg%%:*} lab=""; [ "$ctr" != "$arg" ] && lab=${arg#*:}
+      local d="$OUT/pmcsum_${lab:-x}"; rm -rf "$d"
+      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py --steps 20 --warmup 5 --reps 2 --no-cpu-baseline --no-variants --no-phases --no-power > "$d.json" 2> "$d.err" || { tail -5 "$d.err"; return 1; }
+      python - "$d" "$lab" <<'PY' | tee -a "$OUT/pmcsum.txt"
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "lbm_multi_kernel<4" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print(f"[{sys.argv[2]}] lbm_multi_kernel<4>: " + ", ".join(f"{k} {sum(v) / len(v):.4g} (n={len(v)})" for k, v in sorted(acc.items())))
+PY
+      find "$d" -name '*.csv' -size +200k -delete ;;
+    uselib) cp "mpilattice-boltzmann_amd/lib/variants/$arg.so" mpilattice-boltzmann_amd/lib/liblbm_d2q9.so && echo "now running lib/variants/$arg.so" ;;
     decks)
       for d in 128x128 128x256 256x256 1024x1024; do
         ( cd /tmp && "$GRAFT_REPO_ROOT/mpilattice-boltzmann_amd/bin/d2q9-bgk" "$GRAFT_REPO_ROOT/tests/golden/decks/input_$d.params" "$GRAFT_REPO_ROOT/tests/golden/decks/obstacles_$d.dat" | sed -n '2,3p;6p' | tr '\n' ' '; echo "  [$d]" )
