@@ -28,6 +28,9 @@ on the rank's own device before it is timed, and again after):
   secondary.input_1024x1024
                         BASELINE.json config 4: the shipped 1024x1024 deck, all 20 000 steps, on the same N ranks
                         (p2p and rccl), Reynolds line and av_vels compared with the reference binary's
+At N = 1 the line also carries `sustained` (the headline deck for 3 x >= 2000 steps back to back: what the socket power cap
+leaves) and `secondary.shipped_decks` (BASELINE.json configs 2 - 3: the reference's four input decks through lbm_run, each
+with seconds, us per step, MLUPS, final_state.dat digest == the reference binary's, av_vels under check.py's rule).
 Everything after the headline runs under a time budget (--budget-s): a part that does not fit is recorded as
 skipped, and a watchdog prints the line as far as it got if anything hangs — the driver's run is killed at
 600 s, so the line must be out well before.  The control plane (handles, flags, barriers) is a gloo group:
@@ -79,7 +82,9 @@ def parse_args(argv=None):
                     help="RCCL loop: one all-reduce per (macro-)step instead of one after the loop (north_star wording; measured mode)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra timings: N=1: the other two forms of the sum|u| terms (LBM_FLAG_FAST_AVVELS, LBM_FLAG_EXACT_AVVELS); partitioned runs: the RCCL loop and its per-step all-reduce mode")
-    ap.add_argument("--no-secondary", action="store_true", help="partitioned runs: skip the shipped 1024x1024 deck (BASELINE.json config 4)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures — N=1: the four shipped decks through lbm_run with their acceptance checks (BASELINE.json configs 2-3) "
+                         "and the sustained 3 x 2000-step line; partitioned runs: the shipped 1024x1024 deck on the same ranks (config 4)")
     ap.add_argument("--no-power", action="store_true", help="do not sample the card's socket power / shader clock (hwmon files) during the headline")
     ap.add_argument("--no-phases", action="store_true", help="skip the profiled extra repetition behind `phases` / the per-launch roofline timing")
     ap.add_argument("--secondary-steps", type=int, default=0, help="steps of the 1024x1024 deck (default: its own 20 000)")
@@ -463,10 +468,16 @@ def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, laun
         # (On the 64 x 23 / 768-lane launch the bracketed repetition of a 20-step region runs 20 - 25 % longer than a timed one: an event
         # between two launches keeps the second from being set up behind the first.  The factor is reported: `launch_time_scale`.)
         total_us = sum(float(us) for _, us in launch_profile)
-        if kernel_span_s and total_us > 0 and 0.5 < kernel_span_s * 1e6 / total_us < 1.5:
-            time_scale = kernel_span_s * 1e6 / total_us
+        raw_scale = kernel_span_s * 1e6 / total_us if (kernel_span_s and total_us > 0) else None
+        # accepted band 0.70 .. 1.05: the bracketed repetition can only be LONGER than a timed one, by at most the
+        # 20 - 25 % seen on 20-step regions; a factor outside the band is not applied and the line says so (`launch_time_scale_rejected`)
+        if raw_scale is not None and 0.70 <= raw_scale <= 1.05:
+            time_scale = raw_scale
         for k, us in launch_profile:
             by_k.setdefault(int(k), []).append(float(us) * time_scale)
+        unscaled_by_k: dict[int, list[float]] = {}
+        for k, us in launch_profile:
+            unscaled_by_k.setdefault(int(k), []).append(float(us))
     kernels = (pmc or {}).get("kernels", {})
     family = kernel.split("<")[0]
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": kernel,
@@ -492,10 +503,12 @@ def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, laun
         t = sum(durs) / len(durs) * 1e-6
         entry = kernels.get(name)
         m = {"kernel": name, "launches": len(durs), "avg_launch_ms": t * 1e3, "min_launch_ms": min(durs) * 1e-3,
+             "avg_launch_ms_bracketed_unscaled": sum(unscaled_by_k[k]) / len(unscaled_by_k[k]) * 1e-3,
              "by_section_8d_frac": ALGO_BYTES_PER_CELL * cells_per_launch * k / t / 1e9 / HBM_PEAK_GBS}
         if entry:
             hbm = entry["hbm_bytes_per_launch"] * scale
             m.update({"hbm_bytes_per_launch": hbm, "hbm_GBps": hbm / t / 1e9, "frac_hbm_physical": hbm / t / 1e9 / HBM_PEAK_GBS,
+                      "frac_hbm_physical_bracketed_unscaled": hbm / (m["avg_launch_ms_bracketed_unscaled"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "bytes_per_cell_step": hbm / (cells_per_launch * k)})
             bytes_run += hbm * len(durs)
             time_run += t * len(durs)
@@ -503,6 +516,7 @@ def roofline_object(kernel: str, nx: int, ny: int, cells_per_launch: float, laun
     d = mix[f"K{dominant}"]
     roof.update({"kernel": d["kernel"], "avg_launch_ms": d["avg_launch_ms"], "steps_per_launch": dominant, "run_mix": mix,
                  "launch_time_scale": time_scale,
+                 **({"launch_time_scale_rejected": raw_scale} if (raw_scale is not None and time_scale == 1.0 and abs(raw_scale - 1.0) > 1e-12) else {}),
                  "by_section_8d": {"achieved": d["by_section_8d_frac"] * HBM_PEAK_GBS, "frac": d["by_section_8d_frac"], "unit": "GB/s",
                                    "bytes_per_launch": ALGO_BYTES_PER_CELL * cells_per_launch * dominant,
                                    "note": "SURVEY.md §8(d): 108 B (18 reads + 9 writes) x cells x steps of the launch / its average "
@@ -701,6 +715,7 @@ def main() -> int:
         return sim, (None if ok else (note or "failed on another rank"))
 
     settle_log: dict = {}
+    kernel_spans: dict = {}
 
     def timed(sim, steps: int, reps: int, what: str = "headline"):
         """reps x (barrier + device sync; EXACTLY `steps` steps + the reduction; device sync) -> per-rep seconds, MAX over
@@ -713,6 +728,8 @@ def main() -> int:
         6.4, 6.4 ... ms) and a 1 ms region of an 8-GPU rank's share (1.33, 1.05, 1.10, 1.14, 1.12, 1.08, 1.06, 1.04 ... 0.98 ms
         after twenty) — and W = 5 warm-up steps are 0.3 - 1.6 ms.  The count is agreed on by the ranks from the first run."""
         times, av, err = [], None, None
+        spans = kernel_spans.setdefault(what, [])         # (device ms first..last step kernel, launches) of every repetition, this rank
+        del spans[:]
 
         def one():
             nonlocal av, err
@@ -725,7 +742,12 @@ def main() -> int:
             except lbm.LbmError as e:
                 err = str(e)
             torch.cuda.synchronize()                      # this rank's device work is complete: the reduction made it wait
-            return time.perf_counter() - t0               # for every rank's sums
+            dt = time.perf_counter() - t0                 # for every rank's sums
+            try:
+                spans.append(sim.partition.last_run_kernel_ms())
+            except lbm.LbmError:
+                spans.append((0.0, 0))
+            return dt
 
         settle = 0
         if steps <= 50 and reps > 1:
@@ -769,7 +791,9 @@ def main() -> int:
     sampler = PowerSampler(device_pci_address(local_rank)).start() if rank == 0 and not args.no_power else None
     try:
         times, av = timed(sim, args.steps, args.reps)
-        kernel_ms, launches = sim.partition.last_run_kernel_ms()
+        # the kernel span of the MEDIAN repetition (the one `value` is), not of the last one
+        reps_spans = kernel_spans["headline"][-len(times):]
+        kernel_ms, launches = reps_spans[int(np.argsort(times)[len(times) // 2])]
     except lbm.LbmError as e:
         return fail(f"run: {e}")
     finally:
@@ -778,6 +802,7 @@ def main() -> int:
     assert av.shape == (args.steps,) and np.all(np.isfinite(av)) and np.all(av > 0)
     desc = sim.partition.describe()
     what = sim.describe()
+    sim_layout = dict(sim.layout)
     steps_done = args.warmup + args.steps * (max(1, args.reps) + settle_log.get("headline", 0))
 
     # one more repetition with HIP events around every launch: the per-kernel launch durations behind `roofline`
@@ -839,6 +864,10 @@ def main() -> int:
         # launch over all of the rank's cells, so that bytes and time refer to the same thing
         two_launches = partitioned and (what["p2p"] is None or "edge stream" in what["p2p"])
         n_launch = max(launches // 2 if two_launches else launches, 1)
+        lay = sim_layout
+        if partitioned and lay.get("macro_k", 0) > 0:    # K-step loops: the launches the run's groups hold (the first launch of a group is
+            groups = lbm.plan_groups(lay["macro_k"], lay["ghost"], lay["group"], args.steps)      # an interior + an edge launch: one launch here)
+            n_launch = max(sum(len(g) for g in groups), 1)
         avg_launch_s = kernel_ms / 1e3 / n_launch
         cells_per_launch = float(desc["cells_per_launch"])
         pmc = load_roofline()
@@ -857,17 +886,20 @@ def main() -> int:
                         "rccl": "RCCL send/recv on a side stream, " + ("one all-reduce per macro-step" if what["step_allreduce"] else "one all-reduce after the loop"),
                         "torch": "torch.distributed P2P ops, one all-reduce after the loop", "single": ""}[what["loop"]]
         k = max(what["macro_k"], 1)
+        how = (f"launches of K = {k} steps, one halo exchange per group of up to {sim_layout.get('group', 1)} launches ({sim_layout.get('ghost', 0)} ghost rows: the "
+               f"first launch of a group advances the ghost rows the later ones read)" if what["macro_k"] else "one halo exchange per step")
         if world == 1:
-            part_txt = "single GPU" if not args.ring else f"1-rank ring (self exchange), one k-row halo exchange per macro-step of k steps (K = {k}): {exchange_txt}"
+            part_txt = "single GPU" if not args.ring else f"1-rank ring (self exchange), {how}: {exchange_txt}"
         else:
-            part_txt = f"{world} row blocks (d2q9-bgk.c:834-862), one k-row halo exchange per macro-step of k steps (K = {k}): {exchange_txt}"
+            part_txt = f"{world} row blocks (d2q9-bgk.c:834-862), {how}: {exchange_txt}"
         out = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny, "partitioning": part_txt,
-                       "loop": what["loop"], "macro_k": what["macro_k"], "rccl_nranks": what["rccl_nranks"], "p2p": what["p2p"],
+                       "loop": what["loop"], "macro_k": what["macro_k"], "ghost_rows": sim_layout.get("ghost", 0), "launches_per_exchange": sim_layout.get("group", 1),
+                       "rccl_nranks": what["rccl_nranks"], "p2p": what["p2p"],
                        "step_allreduce": what["step_allreduce"], "kernel": desc["kernel"], "control_plane": backend if world > 1 else None},
             "timing": {"reps": len(times), "settle_reps": settle_log.get("headline", 0),
                        "statistic": "median over reps of (max over ranks of the time of EXACTLY `steps` steps): every rank starts behind a barrier + "
@@ -917,7 +949,6 @@ def main() -> int:
             out["variants"] = variants
             bank(out)
 
-    # ---- partitioned runs: the RCCL loop, and north_star's per-step all-reduce, on the same deck -----------------------
     def optional_part(name: str, need_s: float, body):
         """Run `body` if every rank has `need_s` seconds of budget left; record what happened otherwise.  Rank-symmetric."""
         if min_over_ranks(left()) < need_s:
@@ -932,6 +963,74 @@ def main() -> int:
             res["seconds"] = round(time.time() - t0, 1)
         return res
 
+    # ---- N = 1: what the power cap leaves when the deck runs on and on, and BASELINE.json configs 2 - 3 (the shipped decks) ------
+    def sustained_run():
+        """The headline deck for >= 2000 steps x 3, back to back (a region of seconds, not milliseconds: the socket sits at its power
+        limit and the shader clock settles ~5 % below the short regions'; also long enough for an outside sampler to see the GPU busy)."""
+        n = max(2000, args.steps)
+        s2 = lbm.Simulation(lbm.Params(nx, ny, n, 10, 0.1, 0.005, 1.85), obstacles, device=local_rank, flags=flags)
+        s2.run(args.warmup)
+        sampler2 = PowerSampler(device_pci_address(local_rank)).start() if not args.no_power else None
+        try:
+            t2, _ = timed(s2, n, 3, what="sustained")
+        finally:
+            pw = sampler2.stop() if sampler2 is not None else None
+        s2.close()
+        worst = max(t2)
+        return {"steps_per_rep": n, "reps": 3, "ms_per_rep": [t * 1e3 for t in t2], "value": nx * ny * n / worst / 1e6, "unit": "MLUPS",
+                "ms_per_step": worst / n * 1e3, "statistic": "the SLOWEST of three back-to-back repetitions (the part warms up over them)",
+                **({"power": pw} if pw else {})}
+
+    def shipped_decks():
+        """BASELINE.json configs 2 and 3 (and the other two shipped decks): the reference's own input files through lbm_run on this GPU, whole
+        runs, timed over the reference's window (d2q9-bgk.c:278-398), then its acceptance check — final_state.dat byte for byte against
+        the reference binary's (sha256 in tests/golden/digests.json), the Reynolds line as a string, av_vels against the SHIPPED golden
+        under check/check.py's rule (1 %), and against the reference binary's float run at the sampled steps."""
+        import hashlib
+        import shutil
+        import tempfile
+        dig = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
+        res = {}
+        for name in ("128x128", "128x256", "256x256", "1024x1024"):
+            d = dig[name]
+            p2 = lbm.read_params(os.path.join(DECKS, d["params"]))
+            o2, _ = lbm.read_obstacles(os.path.join(DECKS, d["obstacles"]), p2.nx, p2.ny)
+            s3 = lbm.Simulation(p2, o2, device=local_rank)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            av3 = s3.run(p2.max_iters)
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+            obs = s3.gather_observables()
+            tmp = tempfile.mkdtemp(prefix="lbm_deck_")
+            try:
+                s3.write_values(av3, tmp, observables=obs)
+                h = hashlib.sha256()
+                with open(os.path.join(tmp, "final_state.dat"), "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 20), b""):
+                        h.update(blk)
+                golden = lbm.checker.load_av_vels(os.path.join(ROOT, "tests", "golden", "check", f"{name}.av_vels.dat.gz"))
+                rep = lbm.checker.diff_values(golden, av3)
+                idx = np.asarray(d["av_sample_steps"])
+                res[name] = {"steps": p2.max_iters, "seconds": sec, "us_per_step": sec / p2.max_iters * 1e6,
+                             "value": p2.nx * p2.ny * p2.max_iters / sec / 1e6, "unit": "MLUPS", "kernel": s3.partition.describe()["kernel"],
+                             "final_state_sha256_equals_reference": h.hexdigest() == d["final_state_sha256"],
+                             "reynolds_line_equals_reference": ("Reynolds number:\t\t%.12E" % s3.reynolds(observables=obs)) == d["reynolds_line"],
+                             "av_vels_vs_shipped_golden_max_pct": abs(rep.max_diff_pcnt), "check_py_passes": not rep.failed(1.0),
+                             "av_vels_max_rel_to_reference_samples": float(np.max(np.abs(av3[idx] - np.asarray(d["av_sample_values"])) / np.asarray(d["av_sample_values"]))),
+                             "reference_1core_s_in_build_container": d.get("ref_elapsed_s")}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+                s3.close()
+        return res
+
+    if world == 1 and not args.ring and not args.no_secondary:
+        out["sustained"] = optional_part("sustained: headline deck, 3 x >= 2000 steps", 30.0, sustained_run)
+        bank(out)
+        out["secondary"] = {"shipped_decks": optional_part("secondary: the four shipped decks", 40.0, shipped_decks)}
+        bank(out)
+
+    # ---- partitioned runs: the RCCL loop, and north_star's per-step all-reduce, on the same deck -----------------------
     def variant(mode: str, step_allreduce: bool):
         def body():
             if mode == "rccl" and shared_gpu:

@@ -65,8 +65,10 @@ def main(argv) -> int:
         return 1
     # p2p: direct peer-to-peer halo stores (default); rccl: RCCL send/recv; torch: torch.distributed P2P ops
     exchange = os.environ.get("LBM_EXCHANGE", "auto" if backend == "nccl" or world == 1 else "p2p")
+    # the contract path forms every sum|u| term as the reference does (double precision, d2q9-bgk.c:667); LBM_FLAGS=0: the library's default
+    flags = int(os.environ.get("LBM_FLAGS", lbm._capi.FLAG_EXACT_AVVELS))
     try:
-        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=exchange)
+        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=exchange, flags=flags)
     except lbm.LbmError as e:
         die(str(e))
     if dist is not None:

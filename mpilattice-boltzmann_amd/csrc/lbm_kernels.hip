@@ -139,7 +139,8 @@ struct lbm_ctx {
   int sums_cap = 0;
   double* sums_host = nullptr;   // pinned, sums_cap doubles
   int* counter = nullptr;
-  bool counter_clean = false;   // the device counter is 0 (left so by the last fold of the previous run): begin_run needs no memset
+  bool counter_clean = false;   // the device counter is 0 (left so by the last fold of the previous run, enqueued on counter_clean_stream): a run that
+  hipStream_t counter_clean_stream = nullptr;   // starts on THAT stream needs no memset; on another stream nothing would order its first fold behind the reset
   hipStream_t stream = nullptr;
   // launch-bound grids: kGraphSteps steps captured once into a hipGraph and replayed (one per
   // starting source grid); see lbm_run
@@ -155,7 +156,7 @@ struct lbm_ctx {
   int n_prev = 0;            // partial count of the previous step (0 = nothing to fold)
   int n_prev_vecs = 1;       // ... and how many step vectors of that length the previous launch left (tile kernel: up to 8)
   int multi_K = 0;           // > 0: bandwidth-bound grid advanced K steps per launch by lbm_multi_kernel<K>
-  int multi_tiles_x = 0, multi_tiles = 0;
+  int multi_tiles_x = 0;
   int multi_geom = kGeomStd; // geometry of lbm_multi_kernel's launches (kernels/multi.h): standard, narrow (32-wide tiles), tall (K = 4 on 64 x 23)
   int multi_tx = kMTX;       // its tile width: 64, or 32 for partitions of one round of blocks
   bool multi_tail4 = true;   // lbm_run at K = 3: 4-step launches instead of a 1- or 2-step tail (LBM_TUNE_MULTI_TAIL4)
@@ -428,7 +429,7 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
   if (ensure_sums(c, n_steps)) return 1;
   // the per-step sums of a run go to sums[counter++]: the counter starts at 0.  The last fold of a run leaves it there
   // (fold_last(final)); a memset launch — a kernel boundary on the critical path of a short run — only when it did not
-  if (!c->counter_clean) HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(int), s));
+  if (!c->counter_clean || c->counter_clean_stream != s) HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(int), s));
   c->counter_clean = false;
   c->run_steps = n_steps;
   c->run_done = 0;
@@ -465,6 +466,7 @@ int fold_last(lbm_ctx* c, hipStream_t s, bool final = false)
   c->n_prev = 0;
   c->n_prev_vecs = 1;
   c->counter_clean = final;
+  c->counter_clean_stream = s;
   return 0;
 }
 
@@ -676,8 +678,8 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->fast_avvels = (flags & LBM_FLAG_FAST_AVVELS) != 0;
   c->multi_terms = c->fast_avvels ? kTermsFloat : (flags & LBM_FLAG_EXACT_AVVELS) ? kTermsDouble : kTermsCompensated;
   {
-    const int t = tune_env("LBM_TUNE_TERMS", -1);            // 0 double, 1 float, 2 compensated (A/B runs)
-    if (t >= 0 && t <= 2) c->multi_terms = t;
+    const int t = tune_env("LBM_TUNE_TERMS", -1);            // 0 double, 1 float, 2 compensated (A/B runs of the DEFAULT form:
+    if (t >= 0 && t <= 2 && !(flags & (LBM_FLAG_EXACT_AVVELS | LBM_FLAG_FAST_AVVELS))) c->multi_terms = t;   // a form asked for by flag stays)
   }
   c->accel_row = accel_row;
   c->accel_w1 = p->density * p->accel * 0.111111111111111111111111f;        // d2q9-bgk.c:445
@@ -797,7 +799,6 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tx = geom_tx(c->multi_geom);
     HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
-    c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + 2 * c->ghost + kMinMultiTY - 1) / kMinMultiTY) + 1);
   } else if (!c->tile_kernel && self_periodic && fits_u32 && p->nx < (1 << 23) &&      // (24-bit row multiplies in lbm_multi_kernel)
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
@@ -815,7 +816,6 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     c->multi_tx = geom_tx(c->multi_geom);
     HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
-    c->multi_tiles = c->multi_tiles_x * ((ny_local + kMTY - 1) / kMTY);
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
     // streaming form of the 3-step launch (kernels/sweep.h): strips of 64 columns, segments of rows so that the launch is
     // about one round of two blocks per CU (8192 x 8192: 128 strips x 4 segments of 2048 rows = 512 blocks).
