@@ -56,7 +56,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_CELL = 108.0          # 18 reads + 9 writes of fp32 (BASELINE.json north_star)
 PHYS_BYTES_PER_CELL = 72.125         # 9 reads + 9 writes + 1 mask bit actually moved by a one-step pull kernel
 HBM_PEAK_GBS = 8000.0                # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r03"                # profiles/<round>/roofline.json: the PMC passes the roofline object rests on
+PROFILE_ROUND = "r04"                # profiles/<round>/roofline.json: the PMC passes the roofline object rests on
 DECKS = os.path.join(ROOT, "tests", "golden", "decks")
 
 

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "liblbm_d2q9.so")
+# LBM_LIBRARY: another build of the same ABI in place of the shipped library (tests/experiments_suite.py runs on lib/variants/experiments.so)
+LIB_PATH = os.environ.get("LBM_LIBRARY") or os.path.join(PKG, "lib", "liblbm_d2q9.so")
 
 ABI_VERSION = 4
 NSPEEDS = 9

@@ -16,6 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "liblbm_d2q9.so")
 LIB_RCCL = os.path.join(PKG, "lib", "liblbm_d2q9_rccl.so")
 CLI = os.path.join(PKG, "bin", "d2q9-bgk")
+LIB_EXPERIMENTS = os.path.join(PKG, "lib", "variants", "experiments.so")
 
 # -ffp-contract=off: keep the reference's unfused float arithmetic (bit parity with gcc -std=c99).
 COMMON = ["-O3", "-ffp-contract=off", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
@@ -35,8 +36,8 @@ def _stale(target: str, sources: list[str]) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
-    """Compile the shared library and the CLI if missing or older than their sources."""
+def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> dict[str, str]:
+    """Compile the shared library and the CLI if missing or older than their sources; experiments=True: the experiment build as well."""
     hipcc = _hipcc()
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
@@ -69,7 +70,18 @@ def build(force: bool = False, verbose: bool = False) -> dict[str, str]:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return {"lib": LIB, "lib_rccl": LIB_RCCL, "cli": CLI}
+    out = {"lib": LIB, "lib_rccl": LIB_RCCL, "cli": CLI}
+    if experiments:
+        # the same translation unit with -DLBM_EXPERIMENTS=1: lbm_sweep_kernel and the LDS-staged one-step kernel, which measured slower
+        # than what ships and are kept, with their parity tests (tests/experiments_suite.py), outside liblbm_d2q9.so
+        os.makedirs(os.path.dirname(LIB_EXPERIMENTS), exist_ok=True)
+        if force or _stale(LIB_EXPERIMENTS, lib_src + headers):
+            cmd = [hipcc, "--offload-arch=gfx950", *COMMON, "-DLBM_EXPERIMENTS=1", "-fPIC", "-shared", *lib_src, "-o", LIB_EXPERIMENTS]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        out["lib_experiments"] = LIB_EXPERIMENTS
+    return out
 
 
 if __name__ == "__main__":

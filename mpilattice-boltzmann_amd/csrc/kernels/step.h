@@ -152,6 +152,7 @@ __device__ __forceinline__ double step_cell(const StepArgs& a, int cell)
   return blocked ? 0.0 : term;
 }
 
+#if LBM_EXPERIMENTS   // (not in liblbm_d2q9.so as shipped: never faster than the direct-load form — no value is reused)
 // LDS-staged form (LBM_FLAG_KERNEL_LDS), the tiling BASELINE.json's north_star sentence describes:
 // every global load is 16-byte aligned; the x-1 / x+1 values a lane needs from its neighbours'
 // vectors travel through an LDS tile row with one halo column per side (filled from global memory
@@ -245,6 +246,7 @@ __global__ void __launch_bounds__(kBlock) lbm_step_kernel_lds(const StepArgs a)
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) a.partials_out[wblock] = acc;
 }
+#endif   // LBM_EXPERIMENTS
 
 // The fused streaming-pull step.  Grid: ceil(#quads / (256*iters)) work blocks of 256 lanes (block b
 // owns `iters` consecutive 1024-cell chunks) after one fold block (block 0, dispatched first).

@@ -52,7 +52,12 @@
 #include "kernels/step.h"
 #include "kernels/tile.h"
 #include "kernels/multi.h"
+#ifndef LBM_EXPERIMENTS      // -DLBM_EXPERIMENTS=1 (scripts/build_variant.sh experiments): the forms that measured slower and are kept for the
+#define LBM_EXPERIMENTS 0    // record — lbm_sweep_kernel (LBM_TUNE_SWEEP), lbm_step_kernel_lds (LBM_FLAG_KERNEL_LDS) — with their parity tests
+#endif                       // (tests/experiments_suite.py); liblbm_d2q9.so as shipped does not carry them
+#if LBM_EXPERIMENTS
 #include "kernels/sweep.h"
+#endif
 #include "kernels/aux.h"
 #include "kernels/p2p.h"
 
@@ -252,9 +257,11 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
   if (c->lane_cells == 1) {
     if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel_narrow<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(lbm_step_kernel_narrow<false>, grid, block, 0, s, a);
+#if LBM_EXPERIMENTS
   } else if (c->lds_kernel && a.quad_begin2 >= a.quad_end2) {
     if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel_lds<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(lbm_step_kernel_lds<false>, grid, block, 0, s, a);
+#endif
   } else {
     if (c->nt_stores) hipLaunchKernelGGL(lbm_step_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(lbm_step_kernel<false>, grid, block, 0, s, a);
@@ -360,6 +367,7 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   }
 }
 
+#if LBM_EXPERIMENTS
 // One launch of lbm_sweep_kernel: three steps of a whole periodic grid, strips of 64 columns swept upwards.
 template <int R, int MODE>
 void launch_sweep_r(lbm_ctx* c, bool accel_last, hipStream_t s)
@@ -396,6 +404,8 @@ void launch_sweep(lbm_ctx* c, bool accel_last, hipStream_t s)
   else if (c->sweep_mode == 1) launch_sweep_m<1>(c, accel_last, s);
   else launch_sweep_m<2>(c, accel_last, s);
 }
+
+#endif   // LBM_EXPERIMENTS
 
 template <int T, int H>
 void launch_tile(dim3 grid, hipStream_t s, const TileArgs& a, bool fast)
@@ -714,7 +724,15 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   // (128x128: 3.5 vs 4.4 us/step, 256x256: 4.1 vs 4.6, 512x512: 7.3 vs 6.2 -> cross-over at 64 K cells)
   const size_t narrow_max = static_cast<size_t>(tune_env("LBM_TUNE_NARROW_MAX", 65536));
   c->lane_cells = (p->nx % kCellsPerLane != 0 || c->ncells <= narrow_max) ? 1 : kCellsPerLane;
+#if LBM_EXPERIMENTS
   c->lds_kernel = (flags & LBM_FLAG_KERNEL_LDS) != 0 && c->lane_cells == kCellsPerLane;
+#else
+  if (flags & LBM_FLAG_KERNEL_LDS) {
+    lbm_internal::set_error("lbm_create: LBM_FLAG_KERNEL_LDS needs a library built with -DLBM_EXPERIMENTS=1 (the LDS-staged one-step kernel is never faster and is not shipped)");
+    delete c;
+    return 1;
+  }
+#endif
   // hipGraph replay of 64-step blocks is opt-in: measured on MI355X it changes nothing (128x128:
   // 4.47 vs 4.33 us/step) because even the smallest grids are bound by the device-side kernel
   // boundary + kernel latency, not by the host's launch rate
@@ -817,6 +835,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
     if (c->multi_K > 0) c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + kMinMultiTY - 1) / kMinMultiTY) + 1);
+#if LBM_EXPERIMENTS
     // streaming form of the 3-step launch (kernels/sweep.h): strips of 64 columns, segments of rows so that the launch is
     // about one round of two blocks per CU (8192 x 8192: 128 strips x 4 segments of 2048 rows = 512 blocks).
     // LBM_TUNE_SWEEP = R (rows per tick: 4 or 5); 0 = off (the default: measured 10-20 % slower than lbm_multi_kernel<3>)
@@ -834,6 +853,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
       c->sweep_nseg = nseg; c->sweep_seg_rows = seg_rows;
       c->partials_cap = std::max(c->partials_cap, 3 * strips * nseg + 1);
     }
+#endif   // LBM_EXPERIMENTS
   } else if (c->tile_kernel) {
     c->partials_cap = std::max(c->partials_cap, kMaxTileSteps * c->n_tiles + 1);
     // up to 74 KB of dynamic LDS per block (two 9 x R x R float buffers): above the 64 KB default limit
@@ -949,11 +969,19 @@ int lbm_run(lbm_ctx* c, int n_steps, float* av_vels)
     // with four ghost rows split the same way).
     const int k = next_multi_k(c, n_steps - t);
     hipEvent_t pb = prof_stamp(c, s);
+#if LBM_EXPERIMENTS
     const bool sweep = c->sweep_R > 0 && k == 3;
     if (sweep) launch_sweep(c, /*accel_last=*/t + k < n_steps, s);
-    else launch_multi(c, k, 0, /*accel_last=*/t + k < n_steps, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/true, s);
+    else
+#endif
+    launch_multi(c, k, 0, /*accel_last=*/t + k < n_steps, 0, multi_tiles_for(c, k), 0, 0, /*fold=*/true, s);
     if (c->profile) c->prof_launches.push_back({k, pb, prof_stamp(c, s)});
-    c->n_prev = sweep ? (c->p.nx / kSTX) * c->sweep_nseg : multi_tiles_for(c, k); c->n_prev_vecs = k;
+#if LBM_EXPERIMENTS
+    c->n_prev = sweep ? (c->p.nx / kSTX) * c->sweep_nseg : multi_tiles_for(c, k);
+#else
+    c->n_prev = multi_tiles_for(c, k);
+#endif
+    c->n_prev_vecs = k;
     c->parity ^= 1;
     c->cur ^= 1;
     t += k;
@@ -1478,11 +1506,15 @@ int lbm_describe(const lbm_ctx* c, char* kernel_name, size_t len, long long* cel
 {
   if (!c) { lbm_internal::set_error("lbm_describe: null context"); return 1; }
   if (kernel_name && len) {
+#if LBM_EXPERIMENTS
     if (c->sweep_R > 0 && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_sweep_kernel<%d, fast av_vels>" : "lbm_sweep_kernel<%d>", c->sweep_R);
-    else if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->multi_terms == kTermsFloat ? "lbm_multi_kernel<%d, fast av_vels>" : c->multi_terms == kTermsDouble ? "lbm_multi_kernel<%d, double-precision av_vels terms>" : "lbm_multi_kernel<%d>", c->multi_K);
+    else if (c->lds_kernel && !(c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) && !(c->tile_kernel && c->self_periodic) && c->lane_cells != 1)
+      std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
+    else
+#endif
+    if (c->multi_K > 0 && (c->self_periodic || c->ghost > 0)) std::snprintf(kernel_name, len, c->multi_terms == kTermsFloat ? "lbm_multi_kernel<%d, fast av_vels>" : c->multi_terms == kTermsDouble ? "lbm_multi_kernel<%d, double-precision av_vels terms>" : "lbm_multi_kernel<%d>", c->multi_K);
     else if (c->tile_kernel && c->self_periodic) std::snprintf(kernel_name, len, c->fast_avvels ? "lbm_tile_kernel<%d, %d, fast av_vels>" : "lbm_tile_kernel<%d, %d>", c->tile_T, c->tile_H);
     else if (c->lane_cells == 1) std::snprintf(kernel_name, len, "lbm_step_kernel_narrow<%s>", c->nt_stores ? "true" : "false");
-    else if (c->lds_kernel) std::snprintf(kernel_name, len, "lbm_step_kernel_lds<%s>", c->nt_stores ? "true" : "false");
     else std::snprintf(kernel_name, len, "lbm_step_kernel<%s>", c->nt_stores ? "true" : "false");
   }
   if (cells_per_launch) *cells_per_launch = static_cast<long long>(c->ncells);

@@ -14,6 +14,12 @@
 #   pmc:<counters>:<bench args>   one rocprofv3 --pmc pass of bench.py (its own run, no trace flags)
 #   pmcsum:<counters>[:<tag>]     the same, then the mean per launch of every counter for lbm_multi_kernel<4 (appended to pmcsum.txt)
 #   uselib:<variant>              ON THE BOX: lib/variants/<variant>.so takes the place of lib/liblbm_d2q9.so for the steps that follow
+#   round[:<workload>]            the record behind bench.py's `roofline` for profiles/<tag>/: rocprofv3 --kernel-trace --stats of the default bench.py,
+#                                 FETCH_SIZE / WRITE_SIZE / two SQ --pmc passes at the driver's 20 steps (each its own run), scripts/make_roofline.py,
+#                                 then the default and the driver-style bench lines; everything copied to gpurun_out/<tag>/profiles/
+#   extras                        the secondary figures: 1024x1024 bench line, 1-rank rings (p2p / rccl, with phases) of a rank's share of the
+#                                 8192^2 deck on 2 / 4 / 8 GPUs and of the 1024^2 deck on 8, kernel traces of the two 8-GPU shares, two rank
+#                                 processes on this GPU (the driver's N = 2 line)
 #   decks                         the four shipped decks through bin/d2q9-bgk
 #   fuzz[:<cases>]                scripts/fuzz_kernels.py
 #   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
@@ -88,6 +94,53 @@ print(f"[{sys.argv[2]}] lbm_multi_kernel<4>: " + ", ".join(f"{k} {sum(v) / len(v
 PY
       find "$d" -name '*.csv' -size +200k -delete ;;
     uselib) cp "mpilattice-boltzmann_amd/lib/variants/$arg.so" mpilattice-boltzmann_amd/lib/liblbm_d2q9.so && echo "now running lib/variants/$arg.so" ;;
+    round)
+      local wl=${arg:-8192x8192} P="$OUT/profiles"; mkdir -p "$P"
+      local B="bench.py --workload $wl --no-cpu-baseline --no-variants --no-secondary --reps 1" S="--steps 20 --warmup 5 --reps 2"
+      rm -rf "$OUT/prof" "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq1 "$OUT"/pmc_sq2
+      # the kernel trace runs the DEFAULT region (200 steps x 5 repetitions + warm-up: ~280 launches): launches made while the part ramps
+      # up from idle weigh as little in its average as in bench.py's median
+      timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o trace -- python3 bench.py --workload $wl --no-cpu-baseline --no-variants --no-secondary > "$OUT/prof_bench.json" 2> "$OUT/prof.err" || return 1
+      # the PMC passes run the DRIVER's step count, each in its own run (no trace flags beside --pmc)
+      timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 $B $S > /dev/null 2> "$OUT/pmc_fetch.err" || return 1
+      timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 $B $S > /dev/null 2> "$OUT/pmc_write.err" || return 1
+      timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq1" -o pmc -- python3 $B $S > /dev/null 2> "$OUT/pmc_sq1.err" || return 1
+      timeout -k 10 400 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/pmc_sq2" -o pmc -- python3 $B $S > /dev/null 2> "$OUT/pmc_sq2.err" || return 1
+      local sfx=""; [ "$wl" != 8192x8192 ] && sfx="_$wl"
+      python scripts/make_roofline.py "$TAG" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq1" "$OUT/pmc_sq2" --workload $wl --suffix "$sfx" | tail -12 || return 1
+      find "$OUT/prof" -name '*kernel_stats.csv' -exec cp {} "$P/kernel_stats_bench${sfx:-_8192}.csv" \;
+      find "$OUT/prof" -name '*kernel_trace.csv' -delete; find "$OUT" -path '*pmc_*' -name '*.csv' -size +2000k -delete
+      if [ "$wl" = 8192x8192 ]; then
+        # the bench lines AFTER the PMC passes of this session: roofline.* rests on the counters of the same build on the same box
+        # (bench.py reads profiles/<PROFILE_ROUND>/roofline.json, which make_roofline.py has just written on this box)
+        timeout -k 10 500 python bench.py > "$P/bench_n1.json" 2> "$OUT/bench_n1.err" || { tail -5 "$OUT/bench_n1.err"; return 1; }
+        timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$P/bench_n1_driver_style.json" 2>> "$OUT/bench_n1.err" || return 1
+        cut -c1-300 "$P/bench_n1.json"; echo; cut -c1-200 "$P/bench_n1_driver_style.json"; echo
+      fi
+      cp profiles/$TAG/roofline*.json profiles/$TAG/pmc_*.csv "$P/" ;;
+    extras)
+      local P="$OUT/profiles"; mkdir -p "$P"
+      short() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['config']['loop'], d['config'].get('p2p'), (d.get('parity_check') or {}).get('ok'))" "$1"; }
+      python bench.py --workload 1024x1024 --steps 3000 --warmup 100 --no-cpu-baseline --no-secondary > "$P/bench_1024x1024.json" && short "$P/bench_1024x1024.json" || return 1
+      for wl in 8192x4096 8192x2048 8192x1024 1024x128; do
+        local st=300; [ $wl = 1024x128 ] && st=3000
+        for ex in p2p rccl; do
+          python bench.py --ring --exchange $ex --workload $wl --steps $st --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/ring_${wl}_${ex}.json" && short "$P/ring_${wl}_${ex}.json" || return 1
+        done
+        python bench.py --ring --exchange p2p --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-secondary > "$P/ring_${wl}_p2p_s20.json" && short "$P/ring_${wl}_p2p_s20.json" || return 1
+      done
+      for wl in 8192x1024 1024x128; do
+        local st=300; [ $wl = 1024x128 ] && st=3000
+        python bench.py --ring --exchange rccl --step-allreduce --workload $wl --steps $st --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/ring_${wl}_rccl_step_allreduce.json" && short "$P/ring_${wl}_rccl_step_allreduce.json" || return 1
+        python bench.py --workload $wl --steps $st --warmup 30 --reps 3 --no-cpu-baseline --no-secondary > "$P/single_${wl}.json" && short "$P/single_${wl}.json" || return 1
+        for ex in p2p rccl; do
+          rm -rf "$OUT/prof_ring_${wl}_$ex"
+          timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_ring_${wl}_$ex" -o trace -- python3 bench.py --ring --exchange $ex --workload $wl --steps $st --warmup 30 --reps 1 --no-cpu-baseline --no-verify --no-variants --no-secondary --no-phases > /dev/null 2> "$OUT/prof_ring_${wl}_$ex.err" || return 1
+          find "$OUT/prof_ring_${wl}_$ex" -name '*kernel_stats.csv' -exec cp {} "$P/ring_${wl}_${ex}_kernel_stats.csv" \;
+          find "$OUT/prof_ring_${wl}_$ex" -name '*kernel_trace.csv' -delete
+        done
+      done
+      LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 2 --steps 20 --warmup 5 > "$P/bench_2ranks_one_gpu_8192.json" && short "$P/bench_2ranks_one_gpu_8192.json" ;;
     decks)
       for d in 128x128 128x256 256x256 1024x1024; do
         ( cd /tmp && "$GRAFT_REPO_ROOT/mpilattice-boltzmann_amd/bin/d2q9-bgk" "$GRAFT_REPO_ROOT/tests/golden/decks/input_$d.params" "$GRAFT_REPO_ROOT/tests/golden/decks/obstacles_$d.dat" | sed -n '2,3p;6p' | tr '\n' ' '; echo "  [$d]" )

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>/roofline.json from the rocprofv3 --pmc passes of scripts/gpu_round.sh.
+"""profiles/<tag>/roofline.json from the rocprofv3 --pmc passes of scripts/gpu_session.sh's `round` step.
 
     python scripts/make_roofline.py <tag> gpurun_out/pmc_<tag>_* [--workload 8192x8192]
 
@@ -88,6 +88,7 @@ def main():
     ap.add_argument("tag")
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--workload", default="8192x8192")
+    ap.add_argument("--suffix", default="", help="roofline<suffix>.json (a second workload of the same round, e.g. _1024x1024)")
     a = ap.parse_args()
     nx, ny = (int(v) for v in a.workload.split("x"))
     dst = os.path.join(ROOT, "profiles", a.tag)
@@ -116,7 +117,7 @@ def main():
     dom = max(kernels, key=lambda k: kernels[k]["steps_per_launch"] * kernels[k]["dispatches_profiled"])
     out = {"workload": a.workload, "round": a.tag, "simds": SIMDS, "kernel": dom, "kernels": kernels}
     out.update({k: v for k, v in kernels[dom].items() if k not in ("counters_mean_per_launch", "source")})
-    json.dump(out, open(os.path.join(dst, "roofline.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(dst, f"roofline{a.suffix}.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("source", "counters_mean_per_launch")} for k, v in kernels.items()}, indent=1))
 
 

@@ -631,3 +631,11 @@ def test_groups_of_launches_between_exchanges(lbm, monkeypatch):
     assert (lbm.rank_layout(p, 8, 3)["ghost"], lbm.rank_layout(p, 8, 3)["group"]) == (4, 1)
     monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", "99")
     assert lbm.rank_layout(p, 8, 3)["ghost"] == 16
+
+
+def test_shipped_library_carries_no_experiment_kernels(lbm):
+    """lbm_sweep_kernel and lbm_step_kernel_lds measured slower than what runs by default and are compiled only with -DLBM_EXPERIMENTS=1
+    (scripts/build_variant.sh experiments; their parity tests: tests/experiments_suite.py).  The shipped code object holds neither."""
+    blob = open(lbm.LIB_PATH, "rb").read()
+    assert b"lbm_multi_kernel" in blob and b"lbm_tile_kernel" in blob and b"lbm_step_kernel" in blob
+    assert b"lbm_sweep_kernel" not in blob and b"lbm_step_kernel_lds" not in blob
