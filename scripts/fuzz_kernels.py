@@ -73,7 +73,7 @@ def run_partitions(p, obst, size, steps, kstep):
 
 
 KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_MULTI_TILE",
-         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_SWEEP", "LBM_TUNE_SWEEP_MODE", "LBM_TUNE_SWEEP_BLOCKS"]
+         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_MACRO_GROUP", "LBM_TUNE_SWEEP", "LBM_TUNE_SWEEP_MODE", "LBM_TUNE_SWEEP_BLOCKS"]
 
 
 def main(argv=None) -> int:
@@ -92,17 +92,24 @@ def main(argv=None) -> int:
                 os.environ[k] = v
 
 
+EXPERIMENTS = os.environ.get("LBM_LIBRARY", "").endswith("experiments.so")
+
+
 def fuzz(a) -> int:
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
         kind = rng.choice(["multi", "tile", "ring", "parts", "parts1", "forms", "sweep"])
+        if kind == "sweep" and not EXPERIMENTS:      # lbm_sweep_kernel lives in the experiment build only (LBM_LIBRARY=.../lib/variants/experiments.so)
+            kind = "parts"
         flags_fast = 0
         if kind == "forms":
             # the one-step kernels among themselves: one cell per lane / four cells per lane / LDS-staged, with and
             # without non-temporal stores, any nx (odd too) and ny >= 3
             nx, ny = int(rng.integers(1, 300)), int(rng.integers(3, 120))
             form = rng.choice(["narrow", "vector", "lds", "nt", "no_nt"])
+            if form == "lds" and not EXPERIMENTS:    # (the LDS-staged one-step kernel too)
+                form = "vector"
             env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": "0"}
             if form == "narrow":
                 env["LBM_TUNE_NARROW_MAX"] = str(1 << 30)
@@ -129,7 +136,11 @@ def fuzz(a) -> int:
             K = int(rng.integers(1, 5))
             env = {"LBM_TUNE_TILE_MAX": "0", "LBM_TUNE_MULTI_K": str(K), "LBM_TUNE_MACRO_K": str(max(K, 2) if kind in ("ring", "parts") else K),
                    "LBM_TUNE_MULTI_TILE": str(rng.choice([32, 64])), "LBM_P2P_SCHEDULE": str(rng.choice(["edge", "serial"])),
-                   "LBM_TUNE_MACRO_GHOST": str(rng.choice([0, 4]))}          # 0 -> K ghost rows (tails of 1 and 2 steps), 4 -> four at any K (3s and 4s at K = 3; more ghost rows than steps otherwise)
+                   # ghost rows = steps between two halo exchanges: 0 -> K rows, an exchange before every launch (tails of 1 and 2 steps); 4 -> four at
+                   # any K (3s and 4s at K = 3); more: groups of several launches, the first advancing the ghost rows the later ones read
+                   "LBM_TUNE_MACRO_GHOST": str(rng.choice([0, 4, 7, 8, 12, 16])), "LBM_TUNE_MACRO_GROUP": str(rng.choice([0, 0, 1, 2, 3]))}
+            if env["LBM_TUNE_MACRO_GROUP"] == "0":
+                del env["LBM_TUNE_MACRO_GROUP"]
         steps = int(rng.integers(1, 40))
         dens = float(rng.choice([0.0, 0.002, 0.05, 0.3]))
         p = lbm.Params(nx, ny, steps, 4, float(rng.choice([0.1, 1.0])), float(rng.choice([0.005, 0.05, 0.5])), float(rng.choice([0.7, 1.3, 1.85, 1.97])))

@@ -128,3 +128,13 @@ def test_sweep_kernel_on_shipped_decks(lbm, digests, tmp_path, monkeypatch, name
     assert np.allclose(av[steps], digests[name]["av_sample_values"], rtol=4e-3 if name == "1024x1024" else 5e-4)
 
 
+
+
+def test_randomised_cross_check_with_the_experiment_forms(lbm):
+    """scripts/fuzz_kernels.py on the experiment build: its "sweep" and "lds" cases are drawn only here."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_kernels", os.path.join(ROOT, "scripts", "fuzz_kernels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.EXPERIMENTS and mod.main(["--cases", "60", "--seed", "12"]) == 0
