@@ -1463,7 +1463,8 @@ def test_launch_profile_and_ring_phases(lbm, digests, monkeypatch):
         ph = ring._p2p.phases()
         assert np.max(np.abs(av_r - av_a) / av_a) < AV_EXACT_RTOL
         k = ring.partition.macro_steps
-        assert (ph["macro_steps"], ph["launches"]) == ((3, 6) if k == 3 else (3, 5))   # (4 + 4) + (3 + 3) + (3 + 3), or (4 + 4) + (4 + 4) + 4 (512 x 512: K = 4)
+        groups = lbm.plan_groups(k, ring.layout["ghost"], ring.layout["group"], 20)      # 512 x 512, K = 4 on 16 ghost rows: (4 + 4 + 4 + 4) + 4
+        assert (ph["macro_steps"], ph["launches"]) == (len(groups), sum(len(g) for g in groups)) and ph["launches"] == (6 if k == 3 else 5)
         assert ph["whole_avg"] > 0                                       # the second launch of a group: all tiles, nothing exchanged
         assert ph["host_total"] >= ph["device_span"] > 0 and abs(ph["setup"] + ph["steps"] + ph["reduce"] - ph["device_span"]) < 0.05 * ph["device_span"] + 5.0
         assert ph["interior_avg"] > 0 and ph["push_first"] > 0 and ph["push_avg"] > 0 and (ph["edge_avg"] > 0) == (schedule == "edge")

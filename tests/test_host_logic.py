@@ -484,12 +484,12 @@ def test_bench_roofline_object_weights_the_launch_mix():
     assert abs(r2["by_section_8d"]["frac"] - 108.0 * cells / 8.0 * (20.0 / 7.0) / 150e-6 / 8.0e12) < 1e-9
 
 
-def _pmc_means(directory):
+def _pmc_means(directory, workload="8192"):
     """{kernel full name: ({counter: mean per dispatch}, {counter: mean dispatch seconds})} from the committed rocprofv3 --pmc CSVs."""
     import csv
     import glob
     acc = {}
-    for f in glob.glob(os.path.join(directory, "pmc_*.csv")):
+    for f in glob.glob(os.path.join(directory, f"pmc_*_{workload}.csv")):
         for r in csv.DictReader(open(f)):
             if "lbm_multi_kernel" not in r["Kernel_Name"]:
                 continue
@@ -500,14 +500,14 @@ def _pmc_means(directory):
 
 
 def test_saved_driver_style_line_recomputes_from_the_committed_counter_files():
-    """every roofline.* fraction of a saved driver-style bench line (profiles/r03/bench_n1_driver_style.json:
+    """every roofline.* fraction of a saved driver-style bench line (profiles/r04/bench_n1_driver_style.json:
     --steps 20 --warmup 5 — five lbm_multi_kernel<4> launches since K = 4 became lbm_run's choice; four K = 3 and two K = 4
     before) follows, within 2 %, from the rocprofv3 --pmc CSVs committed beside it and the launch durations the line itself
     states — bytes of each instantiation over ITS OWN duration, the run's fraction weighted by the launches it made, the
     §8(d) figure, the VALU share."""
     import csv
     import json
-    d = os.path.join(ROOT, "profiles", "r03")
+    d = os.path.join(ROOT, "profiles", "r04")
     line = json.load(open(os.path.join(d, "bench_n1_driver_style.json")))
     roof = line["roofline"]
     assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["config"]["nx"] == 8192 == line["config"]["ny"]
@@ -547,6 +547,24 @@ def test_saved_driver_style_line_recomputes_from_the_committed_counter_files():
     assert long_line["roofline"]["kernel"] == roof["kernel"]
     assert abs(long_line["roofline"]["avg_launch_ms"] * 1e6 / avg_ns - 1.0) < 0.10
     assert int(stats[full[dom]]["Calls"]) >= 20
+    # the scaled launch durations come with the bracketed repetition's own, and the factor between them stays inside the band it may take
+    assert 0.70 <= roof["launch_time_scale"] <= 1.05 and "launch_time_scale_rejected" not in roof
+    assert abs(mix[f"K{dom}"]["avg_launch_ms_bracketed_unscaled"] * roof["launch_time_scale"] / mix[f"K{dom}"]["avg_launch_ms"] - 1.0) < 1e-9
+    # the N = 1 line carries BASELINE.json configs 2 - 3 and a sustained figure
+    decks = long_line["secondary"]["shipped_decks"]
+    assert set(decks) >= {"128x128", "128x256", "256x256", "1024x1024"}
+    for name in ("128x128", "128x256", "256x256", "1024x1024"):        # (optional_part adds its own "seconds" beside them)
+        r = decks[name]
+        assert r["final_state_sha256_equals_reference"] is True and r["reynolds_line_equals_reference"] is True and r["check_py_passes"] is True, name
+        assert r["av_vels_vs_shipped_golden_max_pct"] < 1.0 and r["seconds"] > 0 and abs(r["value"] * r["seconds"] * 1e6 / (r["steps"] * int(name.split("x")[0]) * int(name.split("x")[1])) - 1.0) < 1e-9
+    sus = long_line["sustained"]
+    assert sus["steps_per_rep"] >= 2000 and sus["reps"] == 3 and 0.9 < sus["value"] / long_line["value"] <= 1.02
+    # ... and BASELINE.json config 3's "rocprof HBM GB/s vs roofline" at 1024 x 1024: its own PMC passes (Infinity-Cache resident: 72 MiB of state)
+    r1024 = json.load(open(os.path.join(d, "roofline_1024x1024.json")))
+    mean, dur = _pmc_means(d, "1024")[r1024["kernel_full_name"]]
+    hbm = 2.0 * 1024.0 * mean["FETCH_SIZE"] + 1024.0 * mean["WRITE_SIZE"]
+    assert r1024["workload"] == "1024x1024" and r1024["kernel"] == "lbm_multi_kernel<4>" and abs(r1024["hbm_bytes_per_launch"] / hbm - 1.0) < 1e-6
+    assert hbm >= 2 * 36 * 1024 * 1024 * 0.97 and r1024["hbm_bytes_per_cell_step"] < 21.0
 
 
 def test_step_plans_end_in_fours_and_threes(lbm):
