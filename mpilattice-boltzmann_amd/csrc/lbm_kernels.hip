@@ -466,7 +466,9 @@ int fold_last(lbm_ctx* c, hipStream_t s, bool final = false)
 {
   if (c->n_prev == 0) return 0;          // already folded (lbm_step_fold)
   const double* part = c->partials[c->parity ^ 1];
-  if (c->n_prev >= 8192) {
+  // one block folds 23 K partials (4 vectors of an 8192 x 1024-row rank's 5760 tiles) in 31 us — at the end of EVERY run, on the critical
+  // path of a 20-step region; sliced over 64 blocks per vector and folded again it is two launches of a few us (threshold was 8192)
+  if (c->n_prev >= tune_env("LBM_TUNE_FOLD_SLICED_MIN", 1024)) {
     hipLaunchKernelGGL(lbm_fold_slices_kernel, dim3(kFoldSlices, c->n_prev_vecs), dim3(kBlock), 0, s, part, c->n_prev, c->fold_scratch);
     hipLaunchKernelGGL(lbm_fold_kernel, dim3(1), dim3(kBlock), 0, s, c->fold_scratch, kFoldSlices, c->n_prev_vecs, c->sums, c->counter, final ? 1 : 0);
   } else {
