@@ -1100,7 +1100,10 @@ MULTI_GPU_CASES = {
         dict(nx=192, ny=99, K=3, schedule="serial", runs=[7, 24], exchange="rccl"),
         dict(nx=512, ny=70, K=2, schedule="edge", runs=[31], scatter=True, exchange="rccl", step_allreduce=True),
         dict(nx=1024, ny=1024, K=0, schedule="", runs=[13, 2], walls=True, exchange="rccl", step_allreduce=True),
-        dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6], exchange="rccl")],
+        dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6], exchange="rccl"),
+        # four launches per exchange on 16 ghost rows (ranks of 200 rows), over both loops and both schedules; three on 12
+        dict(nx=256, ny=400, K=0, schedule="", runs=[37, 20]), dict(nx=256, ny=400, K=0, schedule="edge", runs=[37, 20], exchange="rccl"),
+        dict(nx=1024, ny=300, K=4, schedule="edge", runs=[21, 20], ghost="12", scatter=True)],
     3: [dict(nx=256, ny=200, K=3, schedule="edge", runs=[20, 11]), dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
         dict(nx=256, ny=200, K=3, schedule="", runs=[20, 11], exchange="rccl", scatter=True),
         dict(nx=1000, ny=400, K=0, schedule="", runs=[16], walls=True, exchange="rccl", step_allreduce=True),
