@@ -8,6 +8,7 @@
 #                                 20 and 200 steps per run — a rank's share of a partitioned run, the wire a self-copy (default grids: 8192x1024 1024x128)
 #   ringsrccl[:<grids>]           the same over the RCCL loop
 #   ring1:<grid>:<steps>:<rounds>:<VAR=val VAR=val ...>   one ring in one process under that environment (wall time per run, as bench.py times it)
+#   single1:<grid>:<steps>:<rounds>:<VAR=val@VAR=val>     the same grid as ONE periodic domain (lbm_run), one process
 #   ringbench:<grid>[:<steps>]    bench.py --ring on one grid (default 20 steps): the line with `phases` in ring_<grid>_s<steps>.json
 #   bench[:<bench.py args>]       bench.py (default: the driver's --steps 20 --warmup 5), the line in bench.json
 #   prof[:<bench.py args>]        rocprofv3 --kernel-trace --stats of bench.py, summary in prof/
@@ -59,6 +60,10 @@ step() {
       local g st ro ev; IFS=: read -r g st ro ev <<< "$arg"
       echo "== ring $g, $st steps per run, env: $ev" | tee -a "$OUT/ring1.txt"
       env ${ev//@/ } timeout -k 10 240 python scripts/ab_ring.py --grid $g --steps $st --rounds $ro - 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a "$OUT/ring1.txt" ;;
+    single1)
+      local g st ro ev; IFS=: read -r g st ro ev <<< "$arg"
+      echo "== single periodic grid $g, $st steps per run, env: $ev" | tee -a "$OUT/single1.txt"
+      env ${ev//@/ } timeout -k 10 240 python scripts/ab_ring.py --single --grid $g --steps $st --rounds $ro - 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a "$OUT/single1.txt" ;;
     ringbench)
       local g=${arg%%:*} st=20; [ "$g" != "$arg" ] && st=${arg#*:}
       timeout -k 10 300 python bench.py --ring --workload $g --steps $st --warmup 5 --no-cpu-baseline --no-variants --no-secondary > "$OUT/ring_${g}_s$st.json" 2> "$OUT/ring_${g}_s$st.err"
