@@ -1031,8 +1031,20 @@ def main() -> int:
         bank(out)
 
     # ---- partitioned runs: the RCCL loop, and north_star's per-step all-reduce, on the same deck -----------------------
-    def variant(mode: str, step_allreduce: bool):
+    def variant(mode: str, step_allreduce: bool, env: dict | None = None):
         def body():
+            saved = {k: os.environ.get(k) for k in (env or {})}
+            os.environ.update(env or {})                    # knobs read at lbm_create; the same on every rank
+            try:
+                return body_inner()
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+
+        def body_inner():
             if mode == "rccl" and shared_gpu:
                 return {"error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"}
             vs, note = set_up(params, obstacles, mode, step_allreduce, args.warmup, flags)
@@ -1041,7 +1053,8 @@ def main() -> int:
             vt, vav = timed(vs, args.steps, args.reps, what=f"variant {mode} {step_allreduce}")
             done = args.warmup + args.steps * (max(1, args.reps) + settle_log.get(f"variant {mode} {step_allreduce}", 0))
             res = {"value": nx * ny * args.steps / float(np.median(vt)) / 1e6, "unit": "MLUPS", "ms_per_step": float(np.median(vt)) / args.steps * 1e3,
-                   "ms_per_rep": [t * 1e3 for t in vt], **{k2: v for k2, v in vs.describe().items() if k2 in ("loop", "macro_k", "rccl_nranks", "step_allreduce")}}
+                   "ms_per_rep": [t * 1e3 for t in vt], **{k2: v for k2, v in vs.describe().items() if k2 in ("loop", "macro_k", "rccl_nranks", "step_allreduce")},
+                   "ghost_rows": vs.layout.get("ghost"), "launches_per_exchange": vs.layout.get("group")}
             if verify_on:
                 good, same, av_err = check_against_single_gpu(vs, params, obstacles, vav, done)
                 res["parity_ok"] = agree(good)
@@ -1051,10 +1064,15 @@ def main() -> int:
 
     if partitioned and not args.no_variants:
         variants = {}
-        for name, mode, sar in (("p2p", "p2p", False), ("rccl", "rccl", False), ("rccl_step_allreduce", "rccl", True)):
-            if (what["loop"], what["step_allreduce"]) == (mode, sar):
+        # p2p_exchange_every_launch: rounds 1-3's loop (K ghost rows, an exchange before every launch) beside round 4's one exchange per
+        # group of launches — on real links the difference is what the deeper halo is worth
+        for name, mode, sar, venv in (("p2p", "p2p", False, None), ("p2p_exchange_every_launch", "p2p", False, {"LBM_TUNE_MACRO_GHOST": "0"}),
+                                      ("rccl", "rccl", False, None), ("rccl_step_allreduce", "rccl", True, None)):
+            if venv is None and (what["loop"], what["step_allreduce"]) == (mode, sar):
                 continue                                   # that is the headline
-            variants[name] = optional_part(f"variant: {name}", 45.0, variant(mode, sar))
+            if venv is not None and (what["loop"] != mode or not what["macro_k"]):
+                continue                                   # (only beside a K-step headline of the same loop)
+            variants[name] = optional_part(f"variant: {name}", 45.0, variant(mode, sar, venv))
             if rank == 0:
                 out["variants"] = variants
                 bank(out)

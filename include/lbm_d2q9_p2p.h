@@ -7,15 +7,19 @@
  * the end-of-run MPI_Reduce (:396) — without a communication library on the path:
  *
  *   - every rank maps its two ring neighbours' grids (hipIpcOpenMemHandle across processes, plain peer
- *     access inside one process) and, once per macro-step of k steps (lbm_macro_next_steps: K, or 3s and 4s), a
- *     small kernel stores its first / last k rows
- *     straight into the neighbours' ghost rows (system-scope stores over the direct xGMI link), then
- *     raises an epoch flag in the neighbour's exported window (release, system scope);
- *   - the consumer's edge launch is preceded on its stream by a one-wave kernel that spins on the two
+ *     access inside one process) and, once per GROUP of launches (lbm_plan_group: the launches between two
+ *     exchanges, r steps together — two 4-step launches on 8 ghost rows by default), a small kernel stores its
+ *     first / last r rows straight into the neighbours' ghost rows (system-scope stores over the direct xGMI
+ *     link), then raises an epoch flag in the neighbour's exported window (release, system scope);
+ *   - the first launch of a group also advances the ghost rows the later launches read, so those are launches
+ *     over all tiles with no exchange in between;
+ *   - the consumer's edge launch is preceded on its stream by the same kernel's wait: one lane spins on the two
  *     flags (acquire, system scope) with a wall-clock bound: a missing peer ends the run with an error
  *     instead of a hang, and no workgroup ever waits for another workgroup of its own launch;
- *   - the two grids are the double buffer (rows for macro-step m+1 land in the grid the consumer does not
- *     read during macro-step m), so the flags only ever travel forward;
+ *   - with one launch per exchange the two grids are the double buffer (rows for group m+1 land in the grid the
+ *     consumer does not read during group m); a group of several launches returns to the grid it started from,
+ *     so a rank tells both neighbours when its ghost rows may be written again — a "ready" word per neighbour,
+ *     said and awaited (bounded) by the fold block of the group's last launch: flags only ever travel forward;
  *   - the end-of-run reduction is an all-gather of the per-step double sums into every rank's window and a
  *     local sum in rank order: bitwise the same vector on every rank, no collective library.
  *
@@ -73,14 +77,16 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step);
  *    3 setup               start of the run -> just before the first step kernel (counter reset, step-0 accelerate_flow)
  *    4 steps               first step kernel -> last step kernel done
  *    5 reduce              last step kernel done -> global sums in host memory (fold + all-gather + sum)
- *    6 macro_steps         COUNT of macro-steps (launch pairs) of the run
+ *    6 macro_steps         COUNT of halo exchanges (groups of launches) of the run
  *    7 macro_step_avg      steps / macro_steps
- *    8 macro_step_steady   the same without the first and the last macro-step (0 with fewer than three)
- *    9 interior_avg        average duration of the interior launches (serial schedule: the one launch over all tiles)
- *   10 edge_avg            ... of the edge launches (0 in the serial schedule)
- *   11 push_first          the push + wait kernel before the first macro-step
+ *    8 macro_step_steady   the same without the first and the last group (0 with fewer than three)
+ *    9 interior_avg        average duration of the interior part of a group's first launch (serial schedule: that launch over all tiles)
+ *   10 edge_avg            ... of its edge part (0 in the serial schedule)
+ *   11 push_first          the push + wait kernel before the first group
  *   12 push_avg            the later push + wait kernels (each includes waiting for both neighbours' rows)
  *   13 host_overhead       host_total - device_span: launch latency before the first event + wake-up after the last
+ *   14 launches            COUNT of step launches (a first launch's two parts count once)
+ *   15 whole_avg           average duration of the later launches of the groups (all tiles, nothing exchanged)
  * One-step mode fills 0-7 only.  lbm_p2p_phase_name(i) returns the names above (NULL past the last). */
 #define LBM_P2P_PHASES 16
 int lbm_p2p_set_profile(lbm_p2p* t, int on);

@@ -1233,6 +1233,10 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
         assert ph["max_over_ranks"][name] > 0, name
     for name in ("rccl", "rccl_step_allreduce"):
         assert "ranks share a GPU" in out["variants"][name]["error"]
+    # rounds 1-3's loop (an exchange before every launch) beside the headline's one exchange per group of launches
+    every = out["variants"]["p2p_exchange_every_launch"]
+    assert every["parity_ok"] is True and (every["ghost_rows"], every["launches_per_exchange"]) == (4, 1) and every["value"] > 0
+    assert (out["config"]["ghost_rows"], out["config"]["launches_per_exchange"]) == (8, 2)
     sec = out["secondary"]["input_1024x1024"]
     assert sec["steps"] == 3000 and sec["p2p"]["parity_ok"] is True and sec["p2p"]["value"] > 0 and "ranks share a GPU" in sec["rccl"]["error"]
 
