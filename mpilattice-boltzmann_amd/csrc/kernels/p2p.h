@@ -7,6 +7,11 @@
 // flags live in an uncached window and are read / written with system-scope atomics; the consumer's data loads
 // happen in a LATER kernel of its stream (kernel boundaries invalidate the non-coherent caches, as they must
 // between any two launches that hand data across XCDs).
+// Round 4: a rank's OWN launches now write ghost rows too (the first launches of a group advance them), rows a peer overwrites one
+// exchange later.  A peer's stores reach this GPU's memory without passing its L2s, so no dirty line of those rows may survive in an
+// XCD's L2 until then: between this rank's last write and the peer's first there is always a kernel boundary of this rank — the
+// "ready" word is said by a LATER launch than any that wrote them — and a kernel boundary writes the L2s back (it must: the next
+// launch's blocks on the other seven XCDs read what this one wrote).
 #pragma once
 #include "common.h"
 
