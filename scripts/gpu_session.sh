@@ -22,7 +22,8 @@
 #                                 8192^2 deck on 2 / 4 / 8 GPUs and of the 1024^2 deck on 8, kernel traces of the two 8-GPU shares, two rank
 #                                 processes on this GPU (the driver's N = 2 line)
 #   decks                         the four shipped decks through bin/d2q9-bgk
-#   fuzz[:<cases>]                scripts/fuzz_kernels.py
+#   fuzz[:<cases>[:<seed>]]       scripts/fuzz_kernels.py
+#   soak                          2000-step runs x 3 of both native loops on a 1-rank ring of 8192x1024 rows, then 4 rank processes on this GPU (400 steps x 5), all parity-checked
 #   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 LBM_P2P_TIMEOUT_MS=${LBM_P2P_TIMEOUT_MS:-10000}
@@ -150,7 +151,19 @@ PY
       for d in 128x128 128x256 256x256 1024x1024; do
         ( cd /tmp && "$GRAFT_REPO_ROOT/mpilattice-boltzmann_amd/bin/d2q9-bgk" "$GRAFT_REPO_ROOT/tests/golden/decks/input_$d.params" "$GRAFT_REPO_ROOT/tests/golden/decks/obstacles_$d.dat" | sed -n '2,3p;6p' | tr '\n' ' '; echo "  [$d]" )
       done | tee "$OUT/cli_decks.txt" ;;
-    fuzz) timeout -k 10 1000 python scripts/fuzz_kernels.py --cases ${arg:-150} --seed 4 2>&1 | grep -v amdgpu.ids | tail -12 | tee "$OUT/fuzz.log" ;;
+    fuzz)
+      local n=${arg%%:*} seed=4; [ "$n" != "$arg" ] && seed=${arg#*:}
+      timeout -k 10 1000 python scripts/fuzz_kernels.py --cases ${n:-150} --seed $seed 2>&1 | grep -v amdgpu.ids | tail -12 | tee "$OUT/fuzz_$seed.log" ;;
+    soak)
+      # long runs of both native loops on an 8-GPU rank's share, parity-checked against a single-GPU run before and after; then four rank
+      # processes sharing this GPU for 400 steps x 5
+      local P="$OUT/profiles"; mkdir -p "$P"
+      for ex in p2p rccl; do
+        timeout -k 10 300 python bench.py --ring --exchange $ex --workload 8192x1024 --steps 2000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary --no-phases > "$P/ring_soak_$ex.json" 2>> "$OUT/soak.err" || return 1
+        python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['parity_check'])" "$P/ring_soak_$ex.json"
+      done
+      LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 4 --workload 4096x4096 --steps 400 --warmup 20 --reps 5 --no-secondary > "$P/bench_4ranks_one_gpu_4096_soak.json" 2>> "$OUT/soak.err" || return 1
+      python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['config']['p2p'], d['parity_check']['ok'], {k: v.get('parity_ok', v.get('error')) for k, v in d['variants'].items()})" "$P/bench_4ranks_one_gpu_4096_soak.json" ;;
     ab)
       local libs=${arg%%:*} rest=""; [ "$libs" != "$arg" ] && rest=${arg#*:}
       timeout -k 10 900 python scripts/ab_libs.py $(echo $libs | tr ',' ' ') $rest 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/ab.txt" ;;
