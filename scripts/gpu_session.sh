@@ -23,6 +23,7 @@
 #                                 processes on this GPU (the driver's N = 2 line)
 #   decks                         the four shipped decks through bin/d2q9-bgk
 #   fuzz[:<cases>[:<seed>]]       scripts/fuzz_kernels.py
+#   timeline[:<bench args>]       per-dispatch start / end of the last 400 kernels of a short bench.py run (default: the 8-GPU share as a ring, 20 steps)
 #   soak                          2000-step runs x 3 of both native loops on a 1-rank ring of 8192x1024 rows, then 4 rank processes on this GPU (400 steps x 5), all parity-checked
 #   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -154,6 +155,21 @@ PY
     fuzz)
       local n=${arg%%:*} seed=4; [ "$n" != "$arg" ] && seed=${arg#*:}
       timeout -k 10 1000 python scripts/fuzz_kernels.py --cases ${n:-150} --seed $seed 2>&1 | grep -v amdgpu.ids | tail -12 | tee "$OUT/fuzz_$seed.log" ;;
+    timeline)
+      # kernel-by-kernel timeline of short runs: rocprofv3 --kernel-trace of <bench args>, the dispatch table kept (timeline.csv: name, start, end in ns)
+      rm -rf "$OUT/timeline"
+      timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/timeline" -o trace -- python3 bench.py ${arg:---ring --workload 8192x1024 --steps 20 --warmup 5 --reps 3 --no-cpu-baseline --no-variants --no-secondary --no-phases --no-verify --no-power} > "$OUT/timeline.json" 2> "$OUT/timeline.err" || return 1
+      python - "$OUT/timeline" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+with open(sys.argv[1] + "/../timeline.csv", "w") as out:
+    out.write("kernel,queue,start_ns,end_ns\n")
+    for r in rows[-400:]:
+        out.write(f'{r["Kernel_Name"][:60].replace(",", ";")},{r.get("Queue_Id", "")},{r["Start_Timestamp"]},{r["End_Timestamp"]}\n')
+print(len(rows), "dispatches; the last 400 in timeline.csv")
+PY
+      rm -rf "$OUT/timeline" ;;
     soak)
       # long runs of both native loops on an 8-GPU rank's share, parity-checked against a single-GPU run before and after; then four rank
       # processes sharing this GPU for 400 steps x 5
