@@ -32,9 +32,6 @@ namespace {
 #ifndef LBM_MTY4           // tile height of the 4-step instantiation, standard and narrow geometry (512 lanes)
 #define LBM_MTY4 13
 #endif
-#ifndef LBM_LDS_ROWMAP     // in-LDS sub-steps: rows dealt to aligned 32-lane groups (1) or lane t -> row t / wp (0: the default).  Round 4, measured:
-#define LBM_LDS_ROWMAP 0   // 1 takes SQ_LDS_BANK_CONFLICT from 90.5 M to 29.0 M cycles per launch (LDS active 240 M -> 179 M) and moves the time by
-#endif                     // nothing: 8192 x 8192 300.4 -> 301.4 us/step, 4096 x 4096 77.4 -> 77.6, 512 x 512 3.16 -> 3.22 (profiles/r04/ab_lds_rowmap.txt)
 #ifndef LBM_MTY4T          // tile height and block size of the 4-step instantiation, tall geometry
 #define LBM_MTY4T 23
 #define LBM_MLANES4T 768
@@ -150,7 +147,14 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
-template <int K, int TERMS, int GEOM>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; GEOM: kGeomStd / Narrow / Tall
+// PART: a launch of a row partition (ghost rows around the owned rows: rows that are computed but belong to the neighbour are not counted;
+// the fold block may carry the peer-to-peer loop's "ready" words).  Whole periodic grids compile without either — and with their row
+// arithmetic spelled as rounds 1 - 3 spelled it (the `PART ? ... : ...` forms below): the first round-4 build, one kernel for both, ran
+// lbm_multi_kernel<4> on 64 x 23 tiles 3 % slower at 8192 x 8192 than round 3's library in the same process (294 against 285.5 us/step);
+// without the counted test and the ready words 1.2 % slower with an instruction count equal to the old kernel's to five in 1 851 —
+// hipcc had scheduled the two bodies differently (110 differing lines in the opcode sequence); with the expressions in their old shape
+// the sequences differ in 7 lines and the times agree (profiles/r04/ab_part_template.txt).  A launch at the socket power limit notices.
+template <int K, int TERMS, int GEOM, bool PART>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; GEOM: kGeomStd / Narrow / Tall
 __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEOM>::waves_per_simd)) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, GEOM>;
@@ -164,8 +168,10 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int tid = threadIdx.x;
 
   if (blockIdx.x == 0) {
-    if (a.ready_epoch != 0ull && tid == 0) {
-      for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if constexpr (PART) {
+      if (a.ready_epoch != 0ull && tid == 0) {
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
     for (int v = 0; v < a.n_prev_vecs; ++v) {
@@ -183,7 +189,9 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     }
     __syncthreads();
     if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
-    if (a.wait_ready && tid == 0) p2p_wait_flags(a.wait_ready, nullptr, 2, a.ready_epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
+    if constexpr (PART) {
+      if (a.wait_ready && tid == 0) p2p_wait_flags(a.wait_ready, nullptr, 2, a.ready_epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
+    }
     return;
   }
 
@@ -200,8 +208,8 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int x0 = tx * TX;
   const int sy0 = a.row_first + ty * TY;          // storage row of the tile's first row
   const int nx = a.nx;
-  const int rows_storage = a.rows_storage;
-  const int row_end = a.row_first + a.rows_compute;   // first storage row past the rows this launch computes
+  const int rows_storage = PART ? a.rows_storage : a.rows_compute + 2 * a.row_first;   // (whole grids: every storage row is computed)
+  [[maybe_unused]] const int row_end = a.row_first + a.rows_compute;   // first storage row past the rows this launch computes
   const int tile_row_base = sy0 * nx;               // block-uniform: a scalar multiply
   const int grid_cells = rows_storage * nx;
   constexpr int ksteps = K;
@@ -213,13 +221,13 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   // does the LDS frame of this tile meet the global accelerate row ny-2 at all ?  (block-uniform)
   bool tile_accel;
   {
-    int d = (a.accel_row - (a.y0s_global + sy0 - EY)) % a.ny_global;        // frame row 0 is storage row sy0 - EY
+    int d = (a.accel_row - (a.y0s_global + (PART ? sy0 : ty * TY) - EY)) % a.ny_global;   // frame row 0 is storage row sy0 - EY (whole grids: sy0 = ty * TY)
     if (d < 0) d += a.ny_global;
     tile_accel = d < G::H || a.ny_global < G::H;
   }
   // storage row -> does it hold the global accelerate row ny-2 ?
   auto on_accel_row = [&](int sr) {
-    int g = a.y0s_global + sr;
+    int g = PART ? a.y0s_global + sr : a.y0s_global + sr - a.row_first;
     if (g < 0) g += a.ny_global; else if (g >= a.ny_global) g -= a.ny_global;
     return g == a.accel_row;
   };
@@ -232,7 +240,7 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
     // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
     const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + TY + EY + 1 <= rows_storage &&
-                       sy0 + TY <= row_end;
+                       sy0 + TY <= a.row_first + a.rows_compute;
     // does every row of the tile count in the sums ?  (block-uniform; false only for the first / last tile rows of a launch that
     // also computes ghost rows)
     const bool all_counted = sy0 >= a.count_first && sy0 + TY <= a.count_end;
@@ -293,15 +301,15 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
       // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
       const int srow = sy0 + fy - EY;                                   // the pair's storage row before any periodic wrap
       const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
-                         (inner || (x0 + fx - EX < nx && srow < row_end));
-      const bool counted = owned && (all_counted || (srow >= a.count_first && srow < a.count_end));
+                         (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.row_first + a.rows_compute));
+      const bool counted = PART ? (owned && (all_counted || (srow >= a.count_first && srow < a.count_end))) : owned;
       bool accel_row_here = false;
       if (tile_accel) accel_row_here = on_accel_row(sr);
       acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, counted ? mbits : 3u, out, acc_lo[0]);
       if (ksteps > 1) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, fy * W, fx, out[k]);
-        pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u | (counted ? 32u : 0u));
+        pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u | ((PART && counted) ? 32u : 0u));
       } else if (owned) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], &at_byte<f2>(a.dstk[k], o_here));
@@ -317,38 +325,22 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     // frame it read kept row r-1 (the frame creeps down one storage row per sub-step), and a region
     // of more than 512 pairs goes in passes of whole rows, bottom to top.  A pass reads, meets at a
     // barrier, then writes; what it overwrites (old rows up to its last row - 1) no later pass reads.
-    auto in_lds_substep = [&](auto j_const) __attribute__((always_inline)) {
-      constexpr int j = decltype(j_const)::value;                        // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
-      constexpr int ey = ksteps - j, ex = 2 * ey;
-      constexpr int wp = (TX + 2 * ex) / 2;                            // pairs per region row
-      constexpr int rows = TY + 2 * ey;
-      constexpr int rpp = kLanes / wp;                                   // whole rows per pass
-      constexpr bool last = j == ksteps;
+    auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
+      const int ey = ksteps - j, ex = 2 * ey;
+      const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
+      const int rows = TY + 2 * ey;
+      const int rpp = kLanes / wp;                                       // whole rows per pass
+      const bool last = j == ksteps;
       const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
-      // Lanes to pairs of a pass (LBM_LDS_ROWMAP = 1: an experiment, bit-exact, no faster — the launch is not LDS-bound).  LDS reads are served in 32-lane groups, one cycle per group unless two lanes of a group meet on a
-      // bank at different addresses: with the pairs of a pass dealt row after row (lane t -> row t / wp) almost every group straddles two
-      // region rows, whose addresses are W - wp (split planes) or W - 2 wp (interleaved ones) dwords apart beyond the lane step — 8 / 4
-      // banks at wp = 36: a two-way conflict in nine groups of ten, 38 % of all LDS cycles (SQ_LDS_BANK_CONFLICT, profiles/r03).  So the
-      // first 32 pairs of every row go to one ALIGNED group of 32 lanes (consecutive dwords: no conflict on either kind of plane), and
-      // the wp - 32 = 4 or 2 pairs left over per row are gathered into the last groups of the pass.
-      // (The leftover groups follow the aligned groups of THE PASS'S OWN rows: behind those of a full pass, the few lanes of a short second
-      // pass would wake a wave of their own — 61 wave-passes per tile instead of 60, which measured +2 % at every size.)
-      constexpr int tailw = LBM_LDS_ROWMAP && wp > 32 && (wp - 32 == 4 || wp - 32 == 2) ? wp - 32 : 0;
-#pragma unroll
+      // lane t -> row t / wp of the pass.  (Round 4 tried rows dealt to ALIGNED 32-lane groups — LDS reads are served in 32-lane groups, and
+      // nine groups of ten straddle two region rows here, a two-way bank conflict each: SQ_LDS_BANK_CONFLICT 90.5 M -> 29.0 M cycles per
+      // launch, LDS-array cycles 240 M -> 179 M, and the launch time unchanged: profiles/r04/ab_lds_rowmap.txt.  Code not kept.)
+      const int ry = tid / wp, rp = tid - ry * wp;
+      const int fx = EX - ex + 2 * rp;
       for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count: unrolled)
-        const int nr = rows - r0 < rpp ? rows - r0 : rpp;                // rows of this pass (a constant once unrolled)
-        int ry, rp;
-        if constexpr (tailw > 0) {
-          const int u = tid - nr * 32;                                   // < 0: one of the aligned groups
-          ry = u < 0 ? (tid >> 5) : u / tailw;                           // (lanes past the pass's pairs: ry >= nr, idle below)
-          rp = u < 0 ? (tid & 31) : 32 + (u & (tailw - 1));
-        } else {
-          ry = tid / wp; rp = tid - ry * wp;
-        }
-        const int fx = EX - ex + 2 * rp;
         f2 outs[9];
         int slot = -1;
-        const bool in_region = ry < nr;
+        const bool in_region = ry < rpp && r0 + ry < rows;
         // whole waves without work skip the pass; in the others every lane computes (an idle lane on the
         // region's first row) and only the write is predicated: no per-lane state to merge at the barrier
         if (__builtin_amdgcn_ballot_w64(in_region) != 0ull) {
@@ -375,7 +367,7 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
           p[6] = f2{lds[6 * kCells + cs - W], lds[6 * kCells + cs - W + WH + 1]};
           p[7] = f2{lds[7 * kCells + cs + W], lds[7 * kCells + cs + W + WH + 1]};
           const bool owned = lane_on && (fl & 4u);
-          const bool counted = lane_on && (fl & 32u);
+          const bool counted = PART ? (lane_on && (fl & 32u)) : owned;
           float term_lo = 0.0f;
           const double term = finish_pair_lo<TERMS>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
                                                     counted ? (fl & 3u) : 3u, outs, term_lo);
@@ -399,10 +391,9 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
       if (!last) __syncthreads();
       LBM_MSTAMP(1 + j);
     };
-    if constexpr (K >= 2) in_lds_substep(std::integral_constant<int, 2>{});
-    if constexpr (K >= 3) in_lds_substep(std::integral_constant<int, 3>{});
-    if constexpr (K >= 4) in_lds_substep(std::integral_constant<int, 4>{});
-    static_assert(K <= 4, "sub-steps 2 .. K are spelled out");
+    // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
+#pragma unroll
+    for (int j = 2; j <= K; ++j) in_lds_substep(j);
   }
 
   // per-step sums over the owned cells of this tile

@@ -269,10 +269,11 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 }
 
 template <int K, int GEOM, int TERMS>
-void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a)
+void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a, bool part)
 {
   using G = MultiGeom<K, GEOM>;
-  lbm_multi_kernel<K, TERMS, GEOM><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  if (part) lbm_multi_kernel<K, TERMS, GEOM, true><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  else lbm_multi_kernel<K, TERMS, GEOM, false><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
 }
 
 // Frames above the default limit of dynamic LDS (the tall geometry: 79 KB) need the limit raised — per DEVICE (a function attribute
@@ -282,8 +283,10 @@ hipError_t raise_multi_lds_limit()
 {
   using G = MultiGeom<K, GEOM>;
   if constexpr (G::lds_bytes > 65536) {
-    const void* fns[3] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM>),
-                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM>)};
+    const void* fns[6] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, false>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, false>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, false>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, true>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, true>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, true>)};
     for (const void* f : fns) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::lds_bytes));
       if (e != hipSuccess) return e;
@@ -293,11 +296,11 @@ hipError_t raise_multi_lds_limit()
 }
 
 template <int K, int GEOM>
-void launch_multi_kg(int blocks, hipStream_t s, const MultiArgs& a, int terms)
+void launch_multi_kg(int blocks, hipStream_t s, const MultiArgs& a, int terms, bool part)
 {
-  if (terms == kTermsFloat) launch_multi_kgt<K, GEOM, kTermsFloat>(blocks, s, a);
-  else if (terms == kTermsDouble) launch_multi_kgt<K, GEOM, kTermsDouble>(blocks, s, a);
-  else launch_multi_kgt<K, GEOM, kTermsCompensated>(blocks, s, a);
+  if (terms == kTermsFloat) launch_multi_kgt<K, GEOM, kTermsFloat>(blocks, s, a, part);
+  else if (terms == kTermsDouble) launch_multi_kgt<K, GEOM, kTermsDouble>(blocks, s, a, part);
+  else launch_multi_kgt<K, GEOM, kTermsCompensated>(blocks, s, a, part);
 }
 
 template <int GEOM>
@@ -318,11 +321,11 @@ hipError_t raise_multi_lds_limits_for(int geom)          // every instantiation 
 }
 
 template <int K>
-void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int geom)
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int geom, bool part)
 {
-  if (geom == kGeomNarrow) launch_multi_kg<K, kGeomNarrow>(blocks, s, a, terms);
-  else if (geom_for(K, geom) == kGeomTall) launch_multi_kg<K, geom_for(K, kGeomTall)>(blocks, s, a, terms);
-  else launch_multi_kg<K, kGeomStd>(blocks, s, a, terms);
+  if (geom == kGeomNarrow) launch_multi_kg<K, kGeomNarrow>(blocks, s, a, terms, part);
+  else if (geom_for(K, geom) == kGeomTall) launch_multi_kg<K, geom_for(K, kGeomTall)>(blocks, s, a, terms, part);
+  else launch_multi_kg<K, kGeomStd>(blocks, s, a, terms, part);
 }
 
 // Tiles of a launch that makes `k` steps on the owned rows and `ext` more rows on each side (ext > 0: a launch of a partitioned
@@ -359,11 +362,12 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
+  const bool part = !c->self_periodic;                         // a row partition: the instantiation that counts owned rows only (kernels/multi.h PART)
   switch (ksteps) {                                            // <= multi_K, or 4 in the tail of a K = 3 run (lbm_run)
-    case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_geom); break;
-    case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_geom); break;
-    case 3: launch_multi_k<3>(blocks, s, a, c->multi_terms, c->multi_geom); break;
-    default: launch_multi_k<4>(blocks, s, a, c->multi_terms, c->multi_geom); break;
+    case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
+    case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
+    case 3: launch_multi_k<3>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
+    default: launch_multi_k<4>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
   }
 }
 

@@ -89,7 +89,7 @@ PY
     pmcsum)
       local ctr=${arg%%:*} lab=""; [ "$ctr" != "$arg" ] && lab=${arg#*:}
       local d="$OUT/pmcsum_${lab:-x}"; rm -rf "$d"
-      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py --steps 20 --warmup 5 --reps 2 --no-cpu-baseline --no-variants --no-phases --no-power > "$d.json" 2> "$d.err" || { tail -5 "$d.err"; return 1; }
+      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py --steps 20 --warmup 5 --reps 2 --no-cpu-baseline --no-variants --no-secondary --no-phases --no-power > "$d.json" 2> "$d.err" || { tail -5 "$d.err"; return 1; }
       python - "$d" "$lab" <<'PY' | tee -a "$OUT/pmcsum.txt"
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
@@ -98,6 +98,23 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         if "lbm_multi_kernel<4" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(f"[{sys.argv[2]}] lbm_multi_kernel<4>: " + ", ".join(f"{k} {sum(v) / len(v):.4g} (n={len(v)})" for k, v in sorted(acc.items())))
+PY
+      find "$d" -name '*.csv' -size +200k -delete ;;
+    pmcab)
+      # counters of two BUILDS in one run: rocprofv3 --pmc <counters> over scripts/ab_libs.py <libs...>; means per kernel name (the builds' names differ)
+      local ctr=${arg%%:*} rest=${arg#*:}
+      case "$ctr" in *FETCH_SIZE*WRITE_SIZE*|*WRITE_SIZE*FETCH_SIZE*) echo "FETCH_SIZE and WRITE_SIZE need separate passes (together the pass hangs)"; return 2 ;; esac
+      local d="$OUT/pmcab_$(echo $ctr | tr ' ' '_' | cut -c1-30)"; rm -rf "$d"
+      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 scripts/ab_libs.py $rest > "$d.txt" 2> "$d.err" || { tail -5 "$d.err"; return 1; }
+      python - "$d" <<'PY' | tee -a "$OUT/pmcab.txt"
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "lbm_multi_kernel<4" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[1] if False else r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in sorted(acc.items()):
+    print(k + ": " + ", ".join(f"{c} {sum(v) / len(v):.5g} (n={len(v)})" for c, v in sorted(cs.items())))
 PY
       find "$d" -name '*.csv' -size +200k -delete ;;
     uselib) cp "mpilattice-boltzmann_amd/lib/variants/$arg.so" mpilattice-boltzmann_amd/lib/liblbm_d2q9.so && echo "now running lib/variants/$arg.so" ;;
