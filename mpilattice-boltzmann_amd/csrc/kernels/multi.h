@@ -105,7 +105,7 @@ struct MultiArgs {
   int rows_storage;            // owned rows + 2 x ghost rows
   int count_first, count_end;
   int y_periodic;
-  int y0s_global, ny_global;   // global row of storage row 0 (may be negative: a rank's bottom ghost rows wrap); global grid height
+  int y0_global, ny_global;    // global row of storage row `row_first` (may be negative: a rank's bottom ghost rows wrap); global grid height
   int tiles_x;
   int tile_begin, tile_count, tile_begin2, tile_count2;   // tile ranges of this launch (second may be empty)
   int ntiles_total;            // stride of partials_out
@@ -147,14 +147,19 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // One launch = exactly K steps (every region size, pass count and accumulator slot is a compile-time
 // constant).  A run whose step count K does not divide ends with a launch of the smaller instantiation
 // lbm_multi_kernel<k>, k < K: its frame needs k-1 <= ghost rows around the tile, so it runs on the same storage.
-// PART: a launch of a row partition (ghost rows around the owned rows: rows that are computed but belong to the neighbour are not counted;
-// the fold block may carry the peer-to-peer loop's "ready" words).  Whole periodic grids compile without either — and with their row
-// arithmetic spelled as rounds 1 - 3 spelled it (the `PART ? ... : ...` forms below): the first round-4 build, one kernel for both, ran
-// lbm_multi_kernel<4> on 64 x 23 tiles 3 % slower at 8192 x 8192 than round 3's library in the same process (294 against 285.5 us/step);
-// without the counted test and the ready words 1.2 % slower with an instruction count equal to the old kernel's to five in 1 851 —
-// hipcc had scheduled the two bodies differently (110 differing lines in the opcode sequence); with the expressions in their old shape
-// the sequences differ in 7 lines and the times agree (profiles/r04/ab_part_template.txt).  A launch at the socket power limit notices.
-template <int K, int TERMS, int GEOM, bool PART>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; GEOM: kGeomStd / Narrow / Tall
+// Launch forms (PART).  The first round-4 build had ONE kernel for grids and partitions — row-range arguments, a `counted` bit beside
+// `owned` in every pair, the peer-to-peer loop's ready words in the fold block — and ran lbm_multi_kernel<4> on 64 x 23 tiles 3 % slower at
+// 8192 x 8192 than round 3's library in the same process (294 against 285.5 us/step); without the counted test and the ready words still
+// 1.2 % slower, with an instruction count equal to the old kernel's to five in 1 851: hipcc had scheduled the two bodies differently (110
+// differing lines in the opcode sequence), and a launch at the socket power limit notices.  Hence: whole grids, and the launches of a
+// partition that compute its owned rows only, compile without either and with their row arithmetic spelled as rounds 1 - 3 spelled it;
+// a launch that also computes ghost rows takes the counted form only in the tiles that hold such rows (its first and last tile rows),
+// chosen by a block-uniform branch; the ready words live in a third instantiation.  Whole grids: back to round 3's time; the 8192 x 1024-row
+// ring 43.4 -> 42.9 us/step beside 40.3 - 41.0 for the same rows as one periodic grid (profiles/r04/ab_part_template.txt).
+// PART = kPartPlain (whole periodic grids, and the launches of a partition that compute its owned rows only), kPartGhost (a launch that
+// also computes ghost rows: the counted test), kPartReady (owned rows only + the ready words in the fold block).
+constexpr int kPartPlain = 0, kPartGhost = 1, kPartReady = 2;
+template <int K, int TERMS, int GEOM, int PART>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; GEOM: kGeomStd / Narrow / Tall
 __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEOM>::waves_per_simd)) lbm_multi_kernel(const MultiArgs a)
 {
   using G = MultiGeom<K, GEOM>;
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int tid = threadIdx.x;
 
   if (blockIdx.x == 0) {
-    if constexpr (PART) {
+    if constexpr (PART == kPartReady) {
       if (a.ready_epoch != 0ull && tid == 0) {
         for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -189,7 +194,7 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     }
     __syncthreads();
     if (tid == 0 && a.n_prev_vecs > 0) *a.counter += a.n_prev_vecs;
-    if constexpr (PART) {
+    if constexpr (PART == kPartReady) {
       if (a.wait_ready && tid == 0) p2p_wait_flags(a.wait_ready, nullptr, 2, a.ready_epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
     }
     return;
@@ -208,7 +213,7 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int x0 = tx * TX;
   const int sy0 = a.row_first + ty * TY;          // storage row of the tile's first row
   const int nx = a.nx;
-  const int rows_storage = PART ? a.rows_storage : a.rows_compute + 2 * a.row_first;   // (whole grids: every storage row is computed)
+  const int rows_storage = PART == kPartGhost ? a.rows_storage : a.rows_compute + 2 * a.row_first;   // (owned rows only: row_first ghost rows on each side)
   [[maybe_unused]] const int row_end = a.row_first + a.rows_compute;   // first storage row past the rows this launch computes
   const int tile_row_base = sy0 * nx;               // block-uniform: a scalar multiply
   const int grid_cells = rows_storage * nx;
@@ -221,179 +226,190 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   // does the LDS frame of this tile meet the global accelerate row ny-2 at all ?  (block-uniform)
   bool tile_accel;
   {
-    int d = (a.accel_row - (a.y0s_global + (PART ? sy0 : ty * TY) - EY)) % a.ny_global;   // frame row 0 is storage row sy0 - EY (whole grids: sy0 = ty * TY)
+    int d = (a.accel_row - (a.y0_global + ty * TY - EY)) % a.ny_global;     // frame row 0 is storage row row_first + ty*TY - EY
     if (d < 0) d += a.ny_global;
     tile_accel = d < G::H || a.ny_global < G::H;
   }
   // storage row -> does it hold the global accelerate row ny-2 ?
   auto on_accel_row = [&](int sr) {
-    int g = PART ? a.y0s_global + sr : a.y0s_global + sr - a.row_first;
+    int g = a.y0_global + sr - a.row_first;
     if (g < 0) g += a.ny_global; else if (g >= a.ny_global) g -= a.ny_global;
     return g == a.accel_row;
   };
 
-  // ---- sub-step 1: pull from the source grid; region = owned tile grown by (ksteps-1) rows / 2(ksteps-1) columns
-  {
-    const int ey = ksteps - 1, ex = 2 * ey;
-    const int wp = (TX + 2 * ex) / 2;                                 // pairs per region row
-    const int np = wp * (TY + 2 * ey);
-    // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
-    // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
-    const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + TY + EY + 1 <= rows_storage &&
-                       sy0 + TY <= a.row_first + a.rows_compute;
-    // does every row of the tile count in the sums ?  (block-uniform; false only for the first / last tile rows of a launch that
-    // also computes ghost rows)
-    const bool all_counted = sy0 >= a.count_first && sy0 + TY <= a.count_end;
-#pragma unroll 1
-    for (int i = tid; i < np; i += kLanes) {
-      const int ry = i / wp, rp = i - ry * wp;
-      const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
-      int gx = x0 + fx - EX;
-      int sr = sy0 + fy - EY;
-      // One multiply per pair, and a 24-bit one (v_mul_lo_u32 and v_mad_u64_u32 issue at quarter rate: the three
-      // products sr * nx, ys * nx, yn * nx were 48 cycles of a pass): the tile's first row is a scalar product, the row
-      // inside the frame a small factor (nx < 2^23 is part of the kernel's eligibility), the rows above and below and
-      // the periodic wraps are additions.
-      int cell = tile_row_base + __mul24(fy - EY, nx) + gx;
-      int d_south = -nx, d_north = nx;
-      if (!inner) {
-        if (gx < 0) { gx += nx; cell += nx; } else if (gx >= nx) { gx -= nx; cell -= nx; }      // periodic (:527-529)
-        // row partition whose rows the tile height does not divide: the last tile row sticks out past the
-        // ghost rows; those cells lie outside every owned cell's dependency cone and are skipped
-        if (!a.y_periodic && sr + 1 >= rows_storage) {
-          if (ksteps > 1) pair_flags[(fy * W + fx) >> 1] = 0;
-          continue;
+  // The K sub-steps, in two forms: COUNT = the tile holds rows that are computed but not counted (a launch that also advances ghost rows:
+  // its first and last tile rows) — every pair then carries a `counted` bit beside `owned`; all other tiles, and every tile of the other
+  // launches, take the form without it, whose schedule is the one rounds 1 - 3 measured (see PART above: the test costs 2 - 3 % when every
+  // tile carries it).  The choice is block-uniform.
+  auto k_substeps = [&](auto count_c) __attribute__((always_inline)) {
+    constexpr bool COUNT = decltype(count_c)::value;
+    // ---- sub-step 1: pull from the source grid; region = owned tile grown by (ksteps-1) rows / 2(ksteps-1) columns
+    {
+      const int ey = ksteps - 1, ex = 2 * ey;
+      const int wp = (TX + 2 * ex) / 2;                                 // pairs per region row
+      const int np = wp * (TY + 2 * ey);
+      // tiles whose frame (and its x -+ 1, y -+ 1 reads) lies inside the grid need none of the periodic
+      // wraps and none of the partial-tile tests: block-uniform fast path for all but the edge tiles
+      const bool inner = x0 - EX >= 2 && x0 + TX + EX + 2 <= nx && sy0 - EY >= 1 && sy0 + TY + EY + 1 <= rows_storage &&
+                         sy0 + TY <= a.row_first + a.rows_compute;
+  #pragma unroll 1
+      for (int i = tid; i < np; i += kLanes) {
+        const int ry = i / wp, rp = i - ry * wp;
+        const int fx = EX - ex + 2 * rp, fy = EY - ey + ry;               // LDS frame coordinates (fx even)
+        int gx = x0 + fx - EX;
+        int sr = sy0 + fy - EY;
+        // One multiply per pair, and a 24-bit one (v_mul_lo_u32 and v_mad_u64_u32 issue at quarter rate: the three
+        // products sr * nx, ys * nx, yn * nx were 48 cycles of a pass): the tile's first row is a scalar product, the row
+        // inside the frame a small factor (nx < 2^23 is part of the kernel's eligibility), the rows above and below and
+        // the periodic wraps are additions.
+        int cell = tile_row_base + __mul24(fy - EY, nx) + gx;
+        int d_south = -nx, d_north = nx;
+        if (!inner) {
+          if (gx < 0) { gx += nx; cell += nx; } else if (gx >= nx) { gx -= nx; cell -= nx; }      // periodic (:527-529)
+          // row partition whose rows the tile height does not divide: the last tile row sticks out past the
+          // ghost rows; those cells lie outside every owned cell's dependency cone and are skipped
+          if (!a.y_periodic && sr + 1 >= rows_storage) {
+            if (ksteps > 1) pair_flags[(fy * W + fx) >> 1] = 0;
+            continue;
+          }
+          if (a.y_periodic) {                                                               // periodic (:245-247)
+            if (sr < 0) { sr += rows_storage; cell += grid_cells; } else if (sr >= rows_storage) { sr -= rows_storage; cell -= grid_cells; }
+            if (sr == 0) d_south = grid_cells - nx;
+            if (sr + 1 >= rows_storage) d_north = nx - grid_cells;
+          }
         }
-        if (a.y_periodic) {                                                               // periodic (:245-247)
-          if (sr < 0) { sr += rows_storage; cell += grid_cells; } else if (sr >= rows_storage) { sr -= rows_storage; cell -= grid_cells; }
-          if (sr == 0) d_south = grid_cells - nx;
-          if (sr + 1 >= rows_storage) d_north = nx - grid_cells;
+        // three 32-bit byte offsets per lane on block-uniform plane bases (scalar base + vector offset
+        // addressing: no 64-bit address arithmetic in the vector unit; the x -+ 1 shifts live in the bases)
+        const uint32_t o_here = 4u * static_cast<uint32_t>(cell);
+        const uint32_t o_south = 4u * static_cast<uint32_t>(cell + d_south);
+        const uint32_t o_north = 4u * static_cast<uint32_t>(cell + d_north);
+        f2 p[9];
+        p[0] = at_byte<f2>(a.srck[0], o_here);                                                   // :530
+        p[2] = at_byte<f2>(a.srck[2], o_south);                                         // :532
+        p[4] = at_byte<f2>(a.srck[4], o_north);                                         // :534
+        p[1] = at_byte<f2u>(a.srck[1] - 1, o_here);                                         // :531
+        p[5] = at_byte<f2u>(a.srck[5] - 1, o_south);                                    // :535
+        p[8] = at_byte<f2u>(a.srck[8] - 1, o_north);                                    // :538
+        p[3] = at_byte<f2u>(a.srck[3] + 1, o_here);                                     // :533
+        p[6] = at_byte<f2u>(a.srck[6] + 1, o_south);                                    // :536
+        p[7] = at_byte<f2u>(a.srck[7] + 1, o_north);                                    // :537
+        if (!inner) {
+          if (gx == 0) {                        // x_w wraps to nx-1 (:529)
+            p[1].x = at_byte<float>(a.srck[1] + nx - 1, o_here); p[5].x = at_byte<float>(a.srck[5] + nx - 1, o_south);
+            p[8].x = at_byte<float>(a.srck[8] + nx - 1, o_north);
+          }
+          if (gx == nx - 2) {                   // x_e wraps to 0 (:527-528)
+            p[3].y = at_byte<float>(a.srck[3] + 2 - nx, o_here); p[6].y = at_byte<float>(a.srck[6] + 2 - nx, o_south);
+            p[7].y = at_byte<float>(a.srck[7] + 2 - nx, o_north);
+          }
         }
-      }
-      // three 32-bit byte offsets per lane on block-uniform plane bases (scalar base + vector offset
-      // addressing: no 64-bit address arithmetic in the vector unit; the x -+ 1 shifts live in the bases)
-      const uint32_t o_here = 4u * static_cast<uint32_t>(cell);
-      const uint32_t o_south = 4u * static_cast<uint32_t>(cell + d_south);
-      const uint32_t o_north = 4u * static_cast<uint32_t>(cell + d_north);
-      f2 p[9];
-      p[0] = at_byte<f2>(a.srck[0], o_here);                                                   // :530
-      p[2] = at_byte<f2>(a.srck[2], o_south);                                         // :532
-      p[4] = at_byte<f2>(a.srck[4], o_north);                                         // :534
-      p[1] = at_byte<f2u>(a.srck[1] - 1, o_here);                                         // :531
-      p[5] = at_byte<f2u>(a.srck[5] - 1, o_south);                                    // :535
-      p[8] = at_byte<f2u>(a.srck[8] - 1, o_north);                                    // :538
-      p[3] = at_byte<f2u>(a.srck[3] + 1, o_here);                                     // :533
-      p[6] = at_byte<f2u>(a.srck[6] + 1, o_south);                                    // :536
-      p[7] = at_byte<f2u>(a.srck[7] + 1, o_north);                                    // :537
-      if (!inner) {
-        if (gx == 0) {                        // x_w wraps to nx-1 (:529)
-          p[1].x = at_byte<float>(a.srck[1] + nx - 1, o_here); p[5].x = at_byte<float>(a.srck[5] + nx - 1, o_south);
-          p[8].x = at_byte<float>(a.srck[8] + nx - 1, o_north);
+        const uint32_t mbits = (at_byte<uint32_t>(a.mask, 4u * (static_cast<uint32_t>(cell) >> 5)) >> (cell & 31)) & 3u;
+        f2 out[9];
+        // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
+        // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
+        const int srow = sy0 + fy - EY;                                   // the pair's storage row before any periodic wrap
+        const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
+                           (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.row_first + a.rows_compute));
+        const bool counted = COUNT ? (owned && srow >= a.count_first && srow < a.count_end) : owned;
+        bool accel_row_here = false;
+        if (tile_accel) accel_row_here = on_accel_row(sr);
+        acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, counted ? mbits : 3u, out, acc_lo[0]);
+        if (ksteps > 1) {
+  #pragma unroll
+          for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, fy * W, fx, out[k]);
+          pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u | ((COUNT && counted) ? 32u : 0u));
+        } else if (owned) {
+  #pragma unroll
+          for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], &at_byte<f2>(a.dstk[k], o_here));
         }
-        if (gx == nx - 2) {                   // x_e wraps to 0 (:527-528)
-          p[3].y = at_byte<float>(a.srck[3] + 2 - nx, o_here); p[6].y = at_byte<float>(a.srck[6] + 2 - nx, o_south);
-          p[7].y = at_byte<float>(a.srck[7] + 2 - nx, o_north);
-        }
-      }
-      const uint32_t mbits = (at_byte<uint32_t>(a.mask, 4u * (static_cast<uint32_t>(cell) >> 5)) >> (cell & 31)) & 3u;
-      f2 out[9];
-      // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
-      // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
-      const int srow = sy0 + fy - EY;                                   // the pair's storage row before any periodic wrap
-      const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
-                         (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.row_first + a.rows_compute));
-      const bool counted = PART ? (owned && (all_counted || (srow >= a.count_first && srow < a.count_end))) : owned;
-      bool accel_row_here = false;
-      if (tile_accel) accel_row_here = on_accel_row(sr);
-      acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, counted ? mbits : 3u, out, acc_lo[0]);
-      if (ksteps > 1) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, fy * W, fx, out[k]);
-        pair_flags[(fy * W + fx) >> 1] = static_cast<uint8_t>(mbits | (owned ? 4u : 0u) | (accel_row_here ? 8u : 0u) | 16u | ((PART && counted) ? 32u : 0u));
-      } else if (owned) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(out[k], &at_byte<f2>(a.dstk[k], o_here));
       }
     }
-  }
-  LBM_MSTAMP(1);
-  if constexpr (K >= 2) {
-    __syncthreads();
-    LBM_MSTAMP(2);
-    // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller.
-    // In place without holding a whole region in registers: sub-step j writes its row r where the
-    // frame it read kept row r-1 (the frame creeps down one storage row per sub-step), and a region
-    // of more than 512 pairs goes in passes of whole rows, bottom to top.  A pass reads, meets at a
-    // barrier, then writes; what it overwrites (old rows up to its last row - 1) no later pass reads.
-    auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
-      const int ey = ksteps - j, ex = 2 * ey;
-      const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
-      const int rows = TY + 2 * ey;
-      const int rpp = kLanes / wp;                                       // whole rows per pass
-      const bool last = j == ksteps;
-      const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
-      // lane t -> row t / wp of the pass.  (Round 4 tried rows dealt to ALIGNED 32-lane groups — LDS reads are served in 32-lane groups, and
-      // nine groups of ten straddle two region rows here, a two-way bank conflict each: SQ_LDS_BANK_CONFLICT 90.5 M -> 29.0 M cycles per
-      // launch, LDS-array cycles 240 M -> 179 M, and the launch time unchanged: profiles/r04/ab_lds_rowmap.txt.  Code not kept.)
-      const int ry = tid / wp, rp = tid - ry * wp;
-      const int fx = EX - ex + 2 * rp;
-      for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count: unrolled)
-        f2 outs[9];
-        int slot = -1;
-        const bool in_region = ry < rpp && r0 + ry < rows;
-        // whole waves without work skip the pass; in the others every lane computes (an idle lane on the
-        // region's first row) and only the write is predicated: no per-lane state to merge at the barrier
-        if (__builtin_amdgcn_ballot_w64(in_region) != 0ull) {
-          const int fy = EY - ey + (in_region ? r0 + ry : 0);
-          const int cf = fy * W + fx;                                    // frame position; stored rd (read) / wr (written) lower
-          const uint32_t fl = pair_flags[cf >> 1];
-          const bool lane_on = in_region && (fl & 16u);
-          // Frame layout, per population: the three that are pulled without an x shift (0, 2, 4) keep their rows
-          // interleaved — a pair is one aligned ds_read_b64.  The six that are pulled from x -+ 1 have their rows stored
-          // DE-INTERLEAVED, odd-x cells first: a row is O[0..WH), E[0..WH) (WH = W/2).  For a pair (x, x+1), x = 2i, the
-          // west pulls are O[i-1], E[i] and the east pulls O[i], E[i+1]: one ds_read2_b32 each, ascending addresses in
-          // lane order (no register swap), lanes on consecutive dwords (interleaved, they were dword pairs at odd
-          // addresses with lane stride 2, two-way bank conflicts in both passes of the instruction).
-          const int ci = cf - rd;                                        // interleaved planes: cell (fx, fy)
-          const int cs = fy * W + (fx >> 1) - rd;                        // split planes: O[i] of row fy; E[i] is WH further
-          f2 p[9];
-          p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + ci);
-          p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + ci - W);
-          p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + ci + W);
-          p[1] = f2{lds[1 * kCells + cs - 1], lds[1 * kCells + cs + WH]};
-          p[5] = f2{lds[5 * kCells + cs - W - 1], lds[5 * kCells + cs - W + WH]};
-          p[8] = f2{lds[8 * kCells + cs + W - 1], lds[8 * kCells + cs + W + WH]};
-          p[3] = f2{lds[3 * kCells + cs], lds[3 * kCells + cs + WH + 1]};
-          p[6] = f2{lds[6 * kCells + cs - W], lds[6 * kCells + cs - W + WH + 1]};
-          p[7] = f2{lds[7 * kCells + cs + W], lds[7 * kCells + cs + W + WH + 1]};
-          const bool owned = lane_on && (fl & 4u);
-          const bool counted = PART ? (lane_on && (fl & 32u)) : owned;
-          float term_lo = 0.0f;
-          const double term = finish_pair_lo<TERMS>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
-                                                    counted ? (fl & 3u) : 3u, outs, term_lo);
-#pragma unroll
-          for (int m = 1; m < K; ++m)
-            if (m == j - 1) { acc[m] += term; acc_lo[m] += term_lo; }
-          // an owned pair lies inside the grid: its cell index needs no periodic wrap
-          slot = !lane_on ? -1 : last ? (owned ? tile_row_base + __mul24(fy - EY, nx) + x0 + fx - EX : -1) : fy * W - wr;   // in LDS: the row; fx is added below
-        }
-        if (!last) {
-          __syncthreads();                     // every lane of the pass has read its neighbours
-          if (slot >= 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, slot, fx, outs[k]);
+    LBM_MSTAMP(1);
+    if constexpr (K >= 2) {
+      __syncthreads();
+      LBM_MSTAMP(2);
+      // ---- sub-steps 2..ksteps: in place in the LDS frame, each on a region one row / two columns smaller.
+      // In place without holding a whole region in registers: sub-step j writes its row r where the
+      // frame it read kept row r-1 (the frame creeps down one storage row per sub-step), and a region
+      // of more than 512 pairs goes in passes of whole rows, bottom to top.  A pass reads, meets at a
+      // barrier, then writes; what it overwrites (old rows up to its last row - 1) no later pass reads.
+      auto in_lds_substep = [&](const int j) __attribute__((always_inline)) {
+        const int ey = ksteps - j, ex = 2 * ey;
+        const int wp = (TX + 2 * ex) / 2;                                // pairs per region row
+        const int rows = TY + 2 * ey;
+        const int rpp = kLanes / wp;                                       // whole rows per pass
+        const bool last = j == ksteps;
+        const int rd = (j - 2) * W, wr = (j - 1) * W;                      // storage shift of the frame read / written
+        // lane t -> row t / wp of the pass.  (Round 4 tried rows dealt to ALIGNED 32-lane groups — LDS reads are served in 32-lane groups, and
+        // nine groups of ten straddle two region rows here, a two-way bank conflict each: SQ_LDS_BANK_CONFLICT 90.5 M -> 29.0 M cycles per
+        // launch, LDS-array cycles 240 M -> 179 M, and the launch time unchanged: profiles/r04/ab_lds_rowmap.txt.  Code not kept.)
+        const int ry = tid / wp, rp = tid - ry * wp;
+        const int fx = EX - ex + 2 * rp;
+        for (int r0 = 0; r0 < rows; r0 += rpp) {        // one or two passes (compile-time count: unrolled)
+          f2 outs[9];
+          int slot = -1;
+          const bool in_region = ry < rpp && r0 + ry < rows;
+          // whole waves without work skip the pass; in the others every lane computes (an idle lane on the
+          // region's first row) and only the write is predicated: no per-lane state to merge at the barrier
+          if (__builtin_amdgcn_ballot_w64(in_region) != 0ull) {
+            const int fy = EY - ey + (in_region ? r0 + ry : 0);
+            const int cf = fy * W + fx;                                    // frame position; stored rd (read) / wr (written) lower
+            const uint32_t fl = pair_flags[cf >> 1];
+            const bool lane_on = in_region && (fl & 16u);
+            // Frame layout, per population: the three that are pulled without an x shift (0, 2, 4) keep their rows
+            // interleaved — a pair is one aligned ds_read_b64.  The six that are pulled from x -+ 1 have their rows stored
+            // DE-INTERLEAVED, odd-x cells first: a row is O[0..WH), E[0..WH) (WH = W/2).  For a pair (x, x+1), x = 2i, the
+            // west pulls are O[i-1], E[i] and the east pulls O[i], E[i+1]: one ds_read2_b32 each, ascending addresses in
+            // lane order (no register swap), lanes on consecutive dwords (interleaved, they were dword pairs at odd
+            // addresses with lane stride 2, two-way bank conflicts in both passes of the instruction).
+            const int ci = cf - rd;                                        // interleaved planes: cell (fx, fy)
+            const int cs = fy * W + (fx >> 1) - rd;                        // split planes: O[i] of row fy; E[i] is WH further
+            f2 p[9];
+            p[0] = *reinterpret_cast<const f2*>(lds + 0 * kCells + ci);
+            p[2] = *reinterpret_cast<const f2*>(lds + 2 * kCells + ci - W);
+            p[4] = *reinterpret_cast<const f2*>(lds + 4 * kCells + ci + W);
+            p[1] = f2{lds[1 * kCells + cs - 1], lds[1 * kCells + cs + WH]};
+            p[5] = f2{lds[5 * kCells + cs - W - 1], lds[5 * kCells + cs - W + WH]};
+            p[8] = f2{lds[8 * kCells + cs + W - 1], lds[8 * kCells + cs + W + WH]};
+            p[3] = f2{lds[3 * kCells + cs], lds[3 * kCells + cs + WH + 1]};
+            p[6] = f2{lds[6 * kCells + cs - W], lds[6 * kCells + cs - W + WH + 1]};
+            p[7] = f2{lds[7 * kCells + cs + W], lds[7 * kCells + cs + W + WH + 1]};
+            const bool owned = lane_on && (fl & 4u);
+            const bool counted = COUNT ? (lane_on && (fl & 32u)) : owned;
+            float term_lo = 0.0f;
+            const double term = finish_pair_lo<TERMS>(p, fl & 3u, a.omega, tile_accel, (!last || a.accel_last) && (fl & 8u), a.accel_w1, a.accel_w2,
+                                                      counted ? (fl & 3u) : 3u, outs, term_lo);
+  #pragma unroll
+            for (int m = 1; m < K; ++m)
+              if (m == j - 1) { acc[m] += term; acc_lo[m] += term_lo; }
+            // an owned pair lies inside the grid: its cell index needs no periodic wrap
+            slot = !lane_on ? -1 : last ? (owned ? tile_row_base + __mul24(fy - EY, nx) + x0 + fx - EX : -1) : fy * W - wr;   // in LDS: the row; fx is added below
           }
-        } else if (slot >= 0) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[k], &at_byte<f2>(a.dstk[k], 4u * static_cast<uint32_t>(slot)));
+          if (!last) {
+            __syncthreads();                     // every lane of the pass has read its neighbours
+            if (slot >= 0) {
+  #pragma unroll
+              for (int k = 0; k < 9; ++k) store_pair<W>(lds + k * kCells, k, slot, fx, outs[k]);
+            }
+          } else if (slot >= 0) {
+  #pragma unroll
+            for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(outs[k], &at_byte<f2>(a.dstk[k], 4u * static_cast<uint32_t>(slot)));
+          }
         }
-      }
-      if (!last) __syncthreads();
-      LBM_MSTAMP(1 + j);
-    };
-    // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
-#pragma unroll
-    for (int j = 2; j <= K; ++j) in_lds_substep(j);
+        if (!last) __syncthreads();
+        LBM_MSTAMP(1 + j);
+      };
+      // compile-time sub-step index: region sizes, `last`, accumulator slot all fold
+  #pragma unroll
+      for (int j = 2; j <= K; ++j) in_lds_substep(j);
+    }
+
+  };
+  if constexpr (PART == kPartGhost) {
+    if (sy0 >= a.count_first && sy0 + TY <= a.count_end) k_substeps(std::false_type{});       // every row of the tile counts
+    else k_substeps(std::true_type{});
+  } else {
+    k_substeps(std::false_type{});
   }
 
   // per-step sums over the owned cells of this tile

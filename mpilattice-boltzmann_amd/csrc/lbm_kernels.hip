@@ -269,11 +269,12 @@ void launch_step(lbm_ctx* c, const StepArgs& a, int blocks, hipStream_t s)
 }
 
 template <int K, int GEOM, int TERMS>
-void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a, bool part)
+void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a, int part)
 {
   using G = MultiGeom<K, GEOM>;
-  if (part) lbm_multi_kernel<K, TERMS, GEOM, true><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
-  else lbm_multi_kernel<K, TERMS, GEOM, false><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  if (part == kPartGhost) lbm_multi_kernel<K, TERMS, GEOM, kPartGhost><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  else if (part == kPartReady) lbm_multi_kernel<K, TERMS, GEOM, kPartReady><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  else lbm_multi_kernel<K, TERMS, GEOM, kPartPlain><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
 }
 
 // Frames above the default limit of dynamic LDS (the tall geometry: 79 KB) need the limit raised — per DEVICE (a function attribute
@@ -283,10 +284,12 @@ hipError_t raise_multi_lds_limit()
 {
   using G = MultiGeom<K, GEOM>;
   if constexpr (G::lds_bytes > 65536) {
-    const void* fns[6] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, false>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, false>),
-                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, false>),
-                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, true>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, true>),
-                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, true>)};
+    const void* fns[9] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartPlain>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartPlain>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartPlain>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartGhost>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartGhost>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartGhost>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartReady>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartReady>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartReady>)};
     for (const void* f : fns) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::lds_bytes));
       if (e != hipSuccess) return e;
@@ -296,7 +299,7 @@ hipError_t raise_multi_lds_limit()
 }
 
 template <int K, int GEOM>
-void launch_multi_kg(int blocks, hipStream_t s, const MultiArgs& a, int terms, bool part)
+void launch_multi_kg(int blocks, hipStream_t s, const MultiArgs& a, int terms, int part)
 {
   if (terms == kTermsFloat) launch_multi_kgt<K, GEOM, kTermsFloat>(blocks, s, a, part);
   else if (terms == kTermsDouble) launch_multi_kgt<K, GEOM, kTermsDouble>(blocks, s, a, part);
@@ -321,7 +324,7 @@ hipError_t raise_multi_lds_limits_for(int geom)          // every instantiation 
 }
 
 template <int K>
-void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int geom, bool part)
+void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, int geom, int part)
 {
   if (geom == kGeomNarrow) launch_multi_kg<K, kGeomNarrow>(blocks, s, a, terms, part);
   else if (geom_for(K, geom) == kGeomTall) launch_multi_kg<K, geom_for(K, kGeomTall)>(blocks, s, a, terms, part);
@@ -344,7 +347,7 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.row_first = c->ghost - ext; a.rows_compute = c->nyl + 2 * ext; a.rows_storage = c->nyl + 2 * c->ghost;
   a.count_first = c->ghost; a.count_end = c->ghost + c->nyl;
   a.y_periodic = c->self_periodic ? 1 : 0;
-  a.y0s_global = c->y0 - c->ghost; a.ny_global = c->p.ny;
+  a.y0_global = c->y0 - ext; a.ny_global = c->p.ny;          // global row of storage row row_first
   a.tiles_x = c->multi_tiles_x;
   a.tile_begin = t0; a.tile_count = n0; a.tile_begin2 = t1; a.tile_count2 = n1;
   a.ntiles_total = multi_tiles_for(c, ksteps, ext);
@@ -362,7 +365,8 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
-  const bool part = !c->self_periodic;                         // a row partition: the instantiation that counts owned rows only (kernels/multi.h PART)
+  // the instantiation (kernels/multi.h PART): ghost rows computed too -> the counted test; ready words to say -> the fold block carries them
+  const int part = ext > 0 ? kPartGhost : a.ready_epoch != 0ull ? kPartReady : kPartPlain;
   switch (ksteps) {                                            // <= multi_K, or 4 in the tail of a K = 3 run (lbm_run)
     case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
     case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
