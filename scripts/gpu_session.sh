@@ -145,6 +145,9 @@ PY
     extras)
       local P="$OUT/profiles"; mkdir -p "$P"
       short() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['config']['loop'], d['config'].get('p2p'), (d.get('parity_check') or {}).get('ok'))" "$1"; }
+      # the whole grid on THIS box, for the ratios (boxes differ by a few per cent): the default region and the driver's
+      python bench.py --no-cpu-baseline --no-variants --no-secondary > "$P/whole_8192x8192.json" && short "$P/whole_8192x8192.json" || return 1
+      python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-secondary > "$P/whole_8192x8192_s20.json" && short "$P/whole_8192x8192_s20.json" || return 1
       python bench.py --workload 1024x1024 --steps 3000 --warmup 100 --no-cpu-baseline --no-secondary > "$P/bench_1024x1024.json" && short "$P/bench_1024x1024.json" || return 1
       for wl in 8192x4096 8192x2048 8192x1024 1024x128; do
         local st=300; [ $wl = 1024x128 ] && st=3000
