@@ -585,8 +585,8 @@ static int macro_k_for(size_t max_cells)
 // ghost rows on each side from the exchanged rows, so the later ones are launches over all tiles that read no exchanged row: no
 // interior / edge split, no push, no wait, no join.  Rounds 1-3 kept K rows (4 at K = 3) and exchanged before every launch.
 //   partitions that run the edge-stream schedule (>= 2 M cells): 2 K rows (8 at K = 3: 3 + 4, 4 + 4, 3 + 3), two launches per exchange —
-//     1-rank ring of 8192 x 1024 rows, us/step at 20 / 200 steps per run for K, 8, 12, 16 rows: 48.5 / 45.3, 46.5 / 43.7, 47.9 / 44.8, 49.0 / 45.1
-//     (12 rows: the first launch's 1040 rows are one tile row more than 1024 or 1032; profiles/r04/rings_p2p_first_build.txt);
+//     1-rank ring of 8192 x 1024 rows, us/step at 20 / 200 steps per run for K, 8, 12, 16 rows: 48.1 / 45.7, 46.8 / 43.8, 46.5 / 43.7, 47.2 / 43.9
+//     (profiles/r04/rings_p2p_final_build.txt: past two launches per exchange nothing more is gained, so the fewest ghost rows stay);
 //   smaller ones (everything on one stream: each exchange is an exposed push + wait): as deep as their rows carry — 16 rows (four
 //     launches per exchange) from 128 rows per rank, 8 from 64, K below (a 32-row rank would compute 56 rows in a group's first launch) —
 //     1024 x 128 rows: 4.85 (K rows), 4.23 (8), 3.85 (12), 3.84 (16) us/step at 200 steps, 6.40 / 6.12 / 5.87 / 5.65 at 20
