@@ -72,7 +72,7 @@ template <int R, bool FAST, int MODE>
 __global__ void __launch_bounds__((SweepGeom<R, MODE>::lanes), (SweepGeom<R, MODE>::waves_per_simd)) lbm_sweep_kernel(const SweepArgs a)
 {
   using G = SweepGeom<R, MODE>;
-  constexpr bool INPLACE = MODE != 0;
+  [[maybe_unused]] constexpr bool INPLACE = MODE != 0;
   constexpr int N = G::ring, W = kSW, kWaves = G::lanes / 64, kPlane = N * W, SW = G::stage_w;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // ring 1 [9][N][W], ring 2 [9][N][W], stage [9][R][SW], then [3][kWaves] doubles
   float* ring1 = lds;
