@@ -59,17 +59,20 @@ struct P2PPushArgs {
 // an 864-block form of this kernel cost 50 us beside the interior launch instead of 8.
 constexpr int kP2PPushBlocks = 64;
 
+template <typename V>      // V = f4 (16-byte accesses: nx a multiple of 4) or f2
 __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, int nx)
 {
   // (Where the launches since the last exchange were more than one, both neighbours have said that their ghost rows may be written
   // before this kernel starts: the fold block of this rank's last launch waited for it, MultiArgs::wait_ready.)
-  const int per_plane = a.nfloats / 2;                         // float2's of one plane's rows (nx even)
+  constexpr int kPer = sizeof(V) / sizeof(float);
+  const int per_plane = a.nfloats / kPer;                      // vectors of one plane's rows
   const int total = per_plane * 18;
   // four independent loads in flight per lane, then their stores: the kernel is a chain of memory round trips
-  // (a 1024 x 4-row message is 295 KB: one pass), not a bandwidth problem
+  // (a 1024 x 4-row message is 295 KB: one pass; a 16-row one three passes of 8-byte accesses, 12 us — 16-byte accesses halve them), not a
+  // bandwidth problem
   constexpr int kUnroll = 4;
   for (int w0 = blockIdx.x * 256 + threadIdx.x; w0 < total; w0 += gridDim.x * 256 * kUnroll) {
-    f2 v[kUnroll];
+    V v[kUnroll];
     float* q[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -78,13 +81,13 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
       if (w < total) {
         const int seg = w / per_plane, i = w - seg * per_plane;
         const int dir = seg / 9, plane = seg - dir * 9;
-        v[u] = *reinterpret_cast<const f2*>(a.src + plane * a.ps + a.src_row[dir] * nx + static_cast<size_t>(i) * 2);
-        q[u] = a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * 2;
+        v[u] = *reinterpret_cast<const V*>(a.src + plane * a.ps + a.src_row[dir] * nx + static_cast<size_t>(i) * kPer);
+        q[u] = a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(i) * kPer;
       }
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u)
-      if (q[u]) *reinterpret_cast<f2*>(q[u]) = v[u];
+      if (q[u]) *reinterpret_cast<V*>(q[u]) = v[u];
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -192,7 +192,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
   a.wait_parity = header_of(t->window)->halo_parity;
   a.timeout_ticks = t->timeout_ticks;
   a.err = t->err;
-  const int work = 18 * (a.nfloats / 2);
+  const bool wide = nx % 4 == 0 && ps.blob.ps % 4 == 0 && pn.blob.ps % 4 == 0 && c->ps % 4 == 0;    // 16-byte accesses (rows and planes 16-byte aligned on both sides)
+  const int work = 18 * (a.nfloats / (wide ? 4 : 2));
   // at most 64 blocks (every block ends with an L2 write-back towards the peers), each lane moving up to four
   // float2's per pass
   // (`exposed`: the push before the first macro-step of a run in the serial schedule, which nothing overlaps)
@@ -200,7 +201,8 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
   // steps per run for 16 / 32 / 64 / 128 blocks: 51.9 / 49.4, 46.9 / 43.5, 47.0 / 43.1, 48.6 / 44.0; profiles/r04/ring_push_blocks.txt)
   const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge * (k > 4 ? 2 : 1) : kP2PPushBlocks;
   const dim3 grid(std::max(1, std::min(max_blocks, (work + 1023) / 1024)));
-  hipLaunchKernelGGL(lbm_p2p_push_kernel, grid, dim3(256), 0, s, a, nx);
+  if (wide) hipLaunchKernelGGL(lbm_p2p_push_kernel<f4>, grid, dim3(256), 0, s, a, nx);
+  else hipLaunchKernelGGL(lbm_p2p_push_kernel<f2>, grid, dim3(256), 0, s, a, nx);
   HIP_TRY(hipGetLastError());
   return 0;
 }
