@@ -228,6 +228,9 @@ int    lbm_macro_unpack(lbm_ctx* ctx, void* stream);
 int    lbm_macro_prepare(lbm_ctx* ctx, int n_steps, void* stream);
 int    lbm_macro_interior(lbm_ctx* ctx, void* stream);
 int    lbm_macro_edge(lbm_ctx* ctx, void* stream);
+/* lbm_macro_interior + lbm_macro_edge as ONE launch over all tiles, for a caller whose exchange is complete before the group's first
+ * launch starts (nothing left to overlap: small ranks on one stream). */
+int    lbm_macro_all(lbm_ctx* ctx, void* stream);
 int    lbm_macro_finish(lbm_ctx* ctx, void* stream);
 int    lbm_macro_exchange_local(lbm_ctx* dst, lbm_ctx* src, int dir, void* stream);
 

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "lbm_macro_steps": (C.c_int, [_ctx]),
     "lbm_macro_next_steps": (C.c_int, [_ctx]),
     "lbm_macro_next_launches": (C.c_int, [_ctx]),
+    "lbm_macro_all": (C.c_int, [_ctx, C.c_void_p]),
     "lbm_macro_halo_floats": (C.c_size_t, [_ctx]),
     "lbm_macro_send_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),
     "lbm_macro_recv_ptr": (C.c_void_p, [_ctx, C.c_int, C.c_int]),

@@ -1417,6 +1417,17 @@ int lbm_macro_edge(lbm_ctx* c, void* stream)
   return 0;
 }
 
+int lbm_macro_all(lbm_ctx* c, void* stream)
+{
+  if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_all: not a K-step context"); return 1; }
+  if (c->run_done >= c->run_steps) { lbm_internal::set_error("lbm_macro_all: no steps left; call lbm_macro_prepare"); return 1; }
+  const GroupPlan g = macro_group(c);
+  launch_group_whole(c, g, 0, c->run_done + g.total < c->run_steps, pick_stream(c, stream));
+  HIP_TRY(hipGetLastError());
+  c->n_prev = 0;
+  return 0;
+}
+
 int lbm_macro_finish(lbm_ctx* c, void* stream)
 {
   if (!c || c->ghost == 0) { lbm_internal::set_error("lbm_macro_finish: not a K-step context"); return 1; }

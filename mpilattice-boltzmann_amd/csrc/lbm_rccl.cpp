@@ -184,7 +184,10 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
   const char* pk = std::getenv("LBM_RCCL_PACK");
   const bool packed = !(pk && pk[0] == '0');              // default: 2 + 2 packed messages; 0 = 18 + 18 direct ones
   const bool three_queues = c->three_queues;
-  hipStream_t edge_stream = three_queues ? c->edge : c->compute;
+  hipStream_t edge_stream = c->edge;
+  // small ranks (one-queue schedule): the exchange goes to the compute stream as well — every hand-off between queues costs 6 - 8 us of idle
+  // queue, and there is no launch long enough to hide the exchange behind (a 1024 x 128-row ring: 26 of 98 us per exchange were hand-offs)
+  hipStream_t xs = three_queues ? c->side : c->compute;
   LBM_TRY(lbm_macro_prepare(ctx, n_steps, c->compute));   // step-0 accelerate_flow
   HIP_TRY(hipEventRecord(c->edge_done, c->compute));
   HIP_TRY(hipEventRecord(c->interior_done, c->compute));
@@ -194,39 +197,45 @@ static int run_macro(lbm_comm* c, int n_steps, double* tot_u_per_step)
     const int launches = lbm_macro_next_launches(ctx);
     if (k <= 0 || launches <= 0) { lbm_internal::set_error("lbm_comm_run: the context has no macro-step left"); return 1; }
     // the rows to send were written by the last launch of the previous group: its edge launch and whatever ran on the compute stream
-    HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));
-    HIP_TRY(hipStreamWaitEvent(c->side, c->interior_done, 0));
+    if (three_queues) {
+      HIP_TRY(hipStreamWaitEvent(c->side, c->edge_done, 0));
+      HIP_TRY(hipStreamWaitEvent(c->side, c->interior_done, 0));
+    }
     if (packed) {
       // gather the 9 planes' rows into one message per direction, exchange 2 + 2 messages, scatter
-      LBM_TRY(lbm_macro_pack(ctx, c->side));
+      LBM_TRY(lbm_macro_pack(ctx, xs));
       NCCL_TRY(ncclGroupStart());                            // order as in the one-step loop: sends [S, N], receives [N, S]
-      NCCL_TRY(ncclSend(lbm_macro_pack_ptr(ctx, 0, 0), np, ncclFloat, c->south, c->nccl, c->side));
-      NCCL_TRY(ncclSend(lbm_macro_pack_ptr(ctx, 1, 0), np, ncclFloat, c->north, c->nccl, c->side));
-      NCCL_TRY(ncclRecv(lbm_macro_pack_ptr(ctx, 1, 1), np, ncclFloat, c->north, c->nccl, c->side));
-      NCCL_TRY(ncclRecv(lbm_macro_pack_ptr(ctx, 0, 1), np, ncclFloat, c->south, c->nccl, c->side));
+      NCCL_TRY(ncclSend(lbm_macro_pack_ptr(ctx, 0, 0), np, ncclFloat, c->south, c->nccl, xs));
+      NCCL_TRY(ncclSend(lbm_macro_pack_ptr(ctx, 1, 0), np, ncclFloat, c->north, c->nccl, xs));
+      NCCL_TRY(ncclRecv(lbm_macro_pack_ptr(ctx, 1, 1), np, ncclFloat, c->north, c->nccl, xs));
+      NCCL_TRY(ncclRecv(lbm_macro_pack_ptr(ctx, 0, 1), np, ncclFloat, c->south, c->nccl, xs));
       NCCL_TRY(ncclGroupEnd());
-      LBM_TRY(lbm_macro_unpack(ctx, c->side));
+      LBM_TRY(lbm_macro_unpack(ctx, xs));
     } else {
       NCCL_TRY(ncclGroupStart());
       for (int q = 0; q < LBM_NSPEEDS; ++q) {                // rows straight into the neighbour's ghost rows
-        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, q), n, ncclFloat, c->south, c->nccl, c->side));
-        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, q), n, ncclFloat, c->north, c->nccl, c->side));
-        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, q), n, ncclFloat, c->north, c->nccl, c->side));
-        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, q), n, ncclFloat, c->south, c->nccl, c->side));
+        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 0, q), n, ncclFloat, c->south, c->nccl, xs));
+        NCCL_TRY(ncclSend(lbm_macro_send_ptr(ctx, 1, q), n, ncclFloat, c->north, c->nccl, xs));
+        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 1, q), n, ncclFloat, c->north, c->nccl, xs));
+        NCCL_TRY(ncclRecv(lbm_macro_recv_ptr(ctx, 0, q), n, ncclFloat, c->south, c->nccl, xs));
       }
       NCCL_TRY(ncclGroupEnd());
     }
-    HIP_TRY(hipEventRecord(c->halo, c->side));
-    if (three_queues && prev_launches == 1) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
-    LBM_TRY(lbm_macro_interior(ctx, c->compute));
-    HIP_TRY(hipStreamWaitEvent(edge_stream, c->halo, 0));
-    if (three_queues) HIP_TRY(hipStreamWaitEvent(c->edge, c->interior_done, 0));
-    LBM_TRY(lbm_macro_edge(ctx, edge_stream));
-    HIP_TRY(hipEventRecord(c->edge_done, edge_stream));
+    if (three_queues) HIP_TRY(hipEventRecord(c->halo, c->side));
+    if (three_queues) {
+      if (prev_launches == 1) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
+      LBM_TRY(lbm_macro_interior(ctx, c->compute));
+      HIP_TRY(hipStreamWaitEvent(edge_stream, c->halo, 0));
+      HIP_TRY(hipStreamWaitEvent(c->edge, c->interior_done, 0));
+      LBM_TRY(lbm_macro_edge(ctx, edge_stream));
+      HIP_TRY(hipEventRecord(c->edge_done, edge_stream));
+    } else {
+      LBM_TRY(lbm_macro_all(ctx, c->compute));               // the exchange is complete in stream order: one launch over all tiles
+    }
     // the later launches of the group (and the last fold of a run) follow on the compute stream and read the edge rows
     if (three_queues && (launches > 1 || done + k >= n_steps)) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
     LBM_TRY(lbm_macro_finish(ctx, c->compute));
-    HIP_TRY(hipEventRecord(c->interior_done, c->compute));
+    if (three_queues) HIP_TRY(hipEventRecord(c->interior_done, c->compute));
     if (c->step_allreduce) {
       // this group's totals now, and the next group behind their all-reduce (north_star wording)
       if (three_queues) HIP_TRY(hipStreamWaitEvent(c->compute, c->edge_done, 0));
