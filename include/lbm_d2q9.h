@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 4
+#define LBM_ABI_VERSION 5
 #define LBM_NSPEEDS 9               /* d2q9-bgk.c:62 */
 
 /* Run constants as read from the parameter file: t_param (d2q9-bgk.c:79-90) minus free_cells_inv,
@@ -136,6 +136,31 @@ int lbm_rank_layout(const lbm_params* p, int nranks, int rank, unsigned flags, l
  * With nranks == 1 the context is a self-contained domain unless LBM_FLAG_FORCE_HALO is set. */
 int lbm_create_rank(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacle_window,
                     int nranks, int rank, int device, unsigned flags);
+
+/* ---- one rank of a TILE (2-D) decomposition: px x py ranks, rank = ry * px + rx ---------------------
+ *
+ * The reference splits rows only (d2q9-bgk.c:834-862); its report discusses a 2-D split for grids wider than tall and never
+ * built it (report.odt, "MPI Design").  Here: rows by the reference's rule over py, columns in whole x-pairs over px
+ * (lbm_decompose_columns), every rank in K-step mode with `ghost` ghost rows AND `ghost_x` ghost columns around its block, refreshed
+ * once per group of launches (lbm_plan_group) by the peer-to-peer loop (lbm_d2q9_p2p.h): columns from the west / east neighbours
+ * first, then whole storage rows — ghost columns included, which carries the corners — from south / north.  px = 1 is allowed
+ * (the rank is its own west and east neighbour); the layout fails where a rank would not be eligible for K-step mode (use the row
+ * decomposition there).  The RCCL loop and the split-phase calls take row partitions only. */
+typedef struct lbm_tile_layout {
+  int px, py, rx, ry;               /* the rank grid and this rank's place in it */
+  int x0, nx_local, y0, ny_local;   /* columns [x0, x0+nx_local) of rows [y0, y0+ny_local) belong to the rank */
+  int macro_k, ghost, group;        /* as lbm_layout */
+  int ghost_x;                      /* ghost columns kept on each side: ghost rounded up to even */
+} lbm_tile_layout;
+int lbm_decompose_columns(int nx, int px, int* nx_local, int* displs);
+int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned flags, lbm_tile_layout* out);
+/* obstacle_window: (ny_local + 2*ghost) rows of (nx_local + 2*ghost_x) ints — global rows y0-ghost .., global columns x0-ghost_x ..,
+ * both wrapping periodically.  lbm_get_cells / lbm_set_cells / lbm_get_observables of such a context move its ny_local x nx_local
+ * block; lbm_state_checksum covers the rank's columns of the rows asked for (the digests of all ranks still add up to the grid's). */
+int lbm_create_tile(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacle_window,
+                    int px, int py, int rank, int device, unsigned flags);
+/* The block a context owns, whichever call created it (px = py = 1, ghost_x = 0 for everything but lbm_create_tile). */
+int lbm_tile_info(const lbm_ctx* ctx, lbm_tile_layout* out);
 
 /* Replaces the whole timestep loop d2q9-bgk.c:315-394 for a self-contained domain
  * (ny_local == ny): n_steps x { accelerate_flow (:442-478); timestep (:493-704); av_vels[tt]

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # LBM_LIBRARY: another build of the same ABI in place of the shipped library (tests/experiments_suite.py runs on lib/variants/experiments.so)
 LIB_PATH = os.environ.get("LBM_LIBRARY") or os.path.join(PKG, "lib", "liblbm_d2q9.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NSPEEDS = 9
 
 FLAG_DEFAULT, FLAG_NT_STORES, FLAG_NO_NT_STORES, FLAG_KERNEL_LDS, FLAG_FORCE_HALO, FLAG_GRAPH, FLAG_ONE_STEP, FLAG_FAST_AVVELS, FLAG_EXACT_AVVELS = 0, 1, 2, 4, 8, 16, 32, 64, 128
@@ -37,6 +37,12 @@ class CLayout(C.Structure):
     _fields_ = [("y0", C.c_int), ("ny_local", C.c_int), ("macro_k", C.c_int), ("ghost", C.c_int), ("group", C.c_int)]
 
 
+class CTileLayout(C.Structure):
+    """struct lbm_tile_layout."""
+
+    _fields_ = [(n, C.c_int) for n in ("px", "py", "rx", "ry", "x0", "nx_local", "y0", "ny_local", "macro_k", "ghost", "group", "ghost_x")]
+
+
 _P = C.POINTER
 _ctx = C.c_void_p
 _SIGNATURES = {
@@ -51,6 +57,10 @@ _SIGNATURES = {
     "lbm_create_global": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_rank_layout": (C.c_int, [_P(CParams), C.c_int, C.c_int, C.c_uint, _P(CLayout)]),
     "lbm_create_rank": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "lbm_decompose_columns": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "lbm_tile_layout_of": (C.c_int, [_P(CParams), C.c_int, C.c_int, C.c_int, C.c_uint, _P(CTileLayout)]),
+    "lbm_create_tile": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "lbm_tile_info": (C.c_int, [_ctx, _P(CTileLayout)]),
     "lbm_destroy": (C.c_int, [_ctx]),
     "lbm_run": (C.c_int, [_ctx, C.c_int, _P(C.c_float)]),
     "lbm_get_cells": (C.c_int, [_ctx, _P(C.c_float)]),

@@ -38,10 +38,12 @@ __global__ void __launch_bounds__(kBlock) lbm_fold_kernel(const double* partials
 }
 
 // accelerate_flow (d2q9-bgk.c:442-478) in place on one row: only needed before the first step of a run.
-__global__ void lbm_accelerate_kernel(float* grid, size_t ps, const uint32_t* mask, int nx, int row, float w1, float w2)
+// Columns [col0, col0 + ncol) of the storage row (a rank of the tile decomposition accelerates its OWNED columns only: its ghost columns of
+// that row arrive accelerated from their owners, possibly before this kernel runs).
+__global__ void lbm_accelerate_kernel(float* grid, size_t ps, const uint32_t* mask, int nx, int row, float w1, float w2, int col0, int ncol)
 {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= nx) return;
+  const int x = col0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= col0 + ncol) return;
   const size_t c = static_cast<size_t>(row) * nx + x;
   if ((mask[c >> 5] >> (c & 31)) & 1u) return;
   float* f = grid + c;
@@ -64,23 +66,34 @@ __global__ void lbm_init_kernel(float* grid, size_t ps, size_t ncells, float w0,
   for (int k = 5; k < 9; ++k) grid[k * ps + i] = w2;
 }
 
-// AoS (reference t_speed) <-> SoA planes.
-__global__ void lbm_aos_to_soa_kernel(const float* aos, float* grid, size_t ps, size_t ncells)
+// A column window of the storage rows: cell c of a dense block of `ncol`-wide rows -> its place in rows of `row_w` floats, `col0`
+// columns in (ranks of the tile decomposition own the columns [ghost_x, ghost_x + nx_local) of their rows; everywhere else
+// row_w == ncol, col0 == 0 and the mapping is the identity).
+struct ColWindow { unsigned row_w, col0, ncol; };
+__device__ __forceinline__ size_t window_cell(const ColWindow w, size_t c)
 {
-  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= ncells * 9) return;
-  const size_t c = i / 9;
-  const int k = static_cast<int>(i - c * 9);
-  grid[k * ps + c] = aos[i];
+  if (w.row_w == w.ncol) return c;
+  const size_t r = c / w.ncol;
+  return r * w.row_w + w.col0 + (c - r * w.ncol);
 }
 
-__global__ void lbm_soa_to_aos_kernel(const float* grid, float* aos, size_t ps, size_t ncells)
+// AoS (reference t_speed) <-> SoA planes.
+__global__ void lbm_aos_to_soa_kernel(const float* aos, float* grid, size_t ps, size_t ncells, ColWindow w)
 {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= ncells * 9) return;
   const size_t c = i / 9;
   const int k = static_cast<int>(i - c * 9);
-  aos[i] = grid[k * ps + c];
+  grid[k * ps + window_cell(w, c)] = aos[i];
+}
+
+__global__ void lbm_soa_to_aos_kernel(const float* grid, float* aos, size_t ps, size_t ncells, ColWindow w)
+{
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= ncells * 9) return;
+  const size_t c = i / 9;
+  const int k = static_cast<int>(i - c * 9);
+  aos[i] = grid[k * ps + window_cell(w, c)];
 }
 
 // Outgoing halo rows of the CURRENT grid (before the first step of a row-partitioned run).
@@ -123,11 +136,12 @@ __global__ void lbm_macro_pack_kernel(const float* grid, float* buf, size_t ps, 
 // av_velocity (d2q9-bgk.c:716-751): per-cell float arithmetic as the reference, double accumulation.
 // Cell c of the owned rows is bit c + bit0 of the obstacle bitfield (K-step partitions: bit0 = ghost*nx,
 // any value, not only multiples of 32).
-__global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t bit0, size_t ncells, double* partials)
+__global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* grid, size_t ps, const uint32_t* mask, size_t bit0, size_t ncells, double* partials, ColWindow w)
 {
   __shared__ double red[kBlock / 64];
   double acc = 0.0;
-  for (size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; c < ncells; c += static_cast<size_t>(gridDim.x) * kBlock) {
+  for (size_t cw = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; cw < ncells; cw += static_cast<size_t>(gridDim.x) * kBlock) {
+    const size_t c = window_cell(w, cw);
     const size_t b = c + bit0;
     if ((mask[b >> 5] >> (b & 31)) & 1u) continue;
     float f[9];
@@ -149,13 +163,14 @@ __global__ void __launch_bounds__(kBlock) lbm_av_velocity_kernel(const float* gr
 // operations in the same order as the reference (division and sqrt correctly rounded), so the values are
 // the bits the host writer computes from the 9 populations.  A NaN produced here from non-NaN inputs
 // (rho = 0) gets the sign x86 gives a generated NaN, which is what the reference's fprintf shows ("-NAN").
-__global__ void __launch_bounds__(kBlock) lbm_observables_kernel(const float* grid, size_t ps, size_t n, float* obs)
+__global__ void __launch_bounds__(kBlock) lbm_observables_kernel(const float* grid, size_t ps, size_t n, float* obs, ColWindow w)
 {
   const size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (c >= n) return;
+  const size_t cs = window_cell(w, c);
   float f[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) f[k] = grid[k * ps + c];
+  for (int k = 0; k < 9; ++k) f[k] = grid[k * ps + cs];
   float rho = 0.0f;
   bool nan_in = false;
 #pragma unroll
@@ -178,14 +193,18 @@ __global__ void __launch_bounds__(kBlock) lbm_observables_kernel(const float* gr
 // so the digests of the ranks of a partitioned run add up to the digest of the whole grid; equal states give
 // equal digests whatever the partitioning, and a single differing bit changes it (with probability 1 - 2^-64).
 __global__ void __launch_bounds__(kBlock) lbm_checksum_kernel(const float* grid, size_t ps, size_t n, unsigned long long global_cell0,
-                                                              unsigned long long* out)
+                                                              unsigned long long* out, ColWindow w, unsigned nx_global)
 {
+  // (global_cell0: the global index of the window's first cell; a window narrower than the grid — a rank of the tile decomposition —
+  // steps nx_global cells per row)
   unsigned long long h = 0;
   for (size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; c < n; c += static_cast<size_t>(gridDim.x) * kBlock) {
+    const size_t cs = window_cell(w, c);
+    const unsigned long long gc = w.row_w == w.ncol ? global_cell0 + c : global_cell0 + (c / w.ncol) * nx_global + (c % w.ncol);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const unsigned long long idx = (global_cell0 + c) * 9ull + static_cast<unsigned long long>(k);
-      unsigned long long z = static_cast<unsigned long long>(__float_as_uint(grid[k * ps + c])) ^ (idx * 0x9E3779B97F4A7C15ull);
+      const unsigned long long idx = gc * 9ull + static_cast<unsigned long long>(k);
+      unsigned long long z = static_cast<unsigned long long>(__float_as_uint(grid[k * ps + cs])) ^ (idx * 0x9E3779B97F4A7C15ull);
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
       z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
       h += z ^ (z >> 31);

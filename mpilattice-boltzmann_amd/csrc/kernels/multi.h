@@ -121,14 +121,20 @@ struct MultiArgs {
   // peer-to-peer loop, the LAST launch of a group of several: "ready for epoch `ready_epoch`" to both neighbours (kernels/p2p.h
   // P2PWindowHeader::halo_ack), said by the fold block as the launch starts — this launch reads ghost rows of its source grid only and
   // writes owned rows, so the ghost rows of its destination grid, the next push's target, are free from here on.  0: nothing to say.
-  unsigned long long* ready[2];
+  unsigned long long* ready[2];  // [0] south, [1] north
   unsigned long long ready_epoch;
   // ... and, once the fold is done, waits until both neighbours have said the same to this rank (bounded; err is the transport's
   // host-mapped error word): the push kernel that follows this launch in the stream then stores without asking.  Every rank speaks
   // before it waits, so a ring of ranks cannot dead-lock here; the wait overlaps the launch's own tiles.
-  const unsigned long long* wait_ready;  // this rank's halo_ack[2], or null
+  const unsigned long long* wait_ready;  // this rank's halo_ack[2] (kPartTile: [4]), or null
   long long timeout_ticks;
   int* err;
+  // Tile decomposition (kPartTile): the storage also has ghost COLUMNS on each side of the owned ones.  The launch computes every
+  // column of its rows (the row wraps at the storage width: what the wrap feeds in is wrong by one more column per step and never
+  // reaches a kept one before the next exchange), KEEPS — writes to the destination grid — the columns [keep_x0, keep_x1) only (owned +
+  // the ghost columns the later launches of the group read; both even), and counts the owned columns [cx0, cx1).
+  int keep_x0, keep_x1, cx0, cx1;
+  unsigned long long* ready_x[2]; // ... and its ready words for the west and the east neighbour (this rank's: wait_ready[2], [3])
 };
 
 // A pair (x, x+1), x even, of population k into row `row` (a dword index) of an LDS frame of row stride W: interleaved
@@ -157,8 +163,10 @@ __device__ __forceinline__ void store_pair(float* plane, int k, int row, int fx,
 // chosen by a block-uniform branch; the ready words live in a third instantiation.  Whole grids: back to round 3's time; the 8192 x 1024-row
 // ring 43.4 -> 42.9 us/step beside 40.3 - 41.0 for the same rows as one periodic grid (profiles/r04/ab_part_template.txt).
 // PART = kPartPlain (whole periodic grids, and the launches of a partition that compute its owned rows only), kPartGhost (a launch that
-// also computes ghost rows: the counted test), kPartReady (owned rows only + the ready words in the fold block).
-constexpr int kPartPlain = 0, kPartGhost = 1, kPartReady = 2;
+// also computes ghost rows: the counted test), kPartReady (owned rows only + the ready words in the fold block), kPartTile (every launch
+// of a rank of the 2-D decomposition: ghost rows AND ghost columns — the counted and kept tests in x as well, in the tiles on the rim of
+// the owned block only — and four ready words; the forms above do not change for it).
+constexpr int kPartPlain = 0, kPartGhost = 1, kPartReady = 2, kPartTile = 3;
 template <int K, int TERMS, int GEOM, int PART>   // TERMS: form of the sum|u| terms (kTermsCompensated by default), see finish_pair_lo; GEOM: kGeomStd / Narrow / Tall
 __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEOM>::waves_per_simd)) lbm_multi_kernel(const MultiArgs a)
 {
@@ -176,6 +184,12 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     if constexpr (PART == kPartReady) {
       if (a.ready_epoch != 0ull && tid == 0) {
         for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if constexpr (PART == kPartTile) {
+      if (a.ready_epoch != 0ull && tid == 0) {
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.ready_x[d], a.ready_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     // fold block: the previous launch's per-tile sums, one vector per step, into sums[counter..]
@@ -197,6 +211,9 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     if constexpr (PART == kPartReady) {
       if (a.wait_ready && tid == 0) p2p_wait_flags(a.wait_ready, nullptr, 2, a.ready_epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
     }
+    if constexpr (PART == kPartTile) {
+      if (a.wait_ready && tid == 0) p2p_wait_flags(a.wait_ready, nullptr, 4, a.ready_epoch, 0ull, a.timeout_ticks, a.err, /*acquire=*/false);
+    }
     return;
   }
 
@@ -213,7 +230,8 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   const int x0 = tx * TX;
   const int sy0 = a.row_first + ty * TY;          // storage row of the tile's first row
   const int nx = a.nx;
-  const int rows_storage = PART == kPartGhost ? a.rows_storage : a.rows_compute + 2 * a.row_first;   // (owned rows only: row_first ghost rows on each side)
+  constexpr bool XR = PART == kPartTile;            // ghost columns: kept / counted column ranges
+  const int rows_storage = (PART == kPartGhost || PART == kPartTile) ? a.rows_storage : a.rows_compute + 2 * a.row_first;   // (owned rows only: row_first ghost rows on each side)
   [[maybe_unused]] const int row_end = a.row_first + a.rows_compute;   // first storage row past the rows this launch computes
   const int tile_row_base = sy0 * nx;               // block-uniform: a scalar multiply
   const int grid_cells = rows_storage * nx;
@@ -308,9 +326,15 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
         // owned = inside the tile AND inside the grid (the last tile column / row may stick out of a grid
         // whose edges are not multiples of the tile: those cells are periodic images, computed but not kept)
         const int srow = sy0 + fy - EY;                                   // the pair's storage row before any periodic wrap
-        const bool owned = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
-                           (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.row_first + a.rows_compute));
-        const bool counted = COUNT ? (owned && srow >= a.count_first && srow < a.count_end) : owned;
+        const bool owned_rows = fx >= EX && fx < EX + TX && fy >= EY && fy < EY + TY &&
+                                (inner || (x0 + fx - EX < nx && sy0 + fy - EY < a.row_first + a.rows_compute));
+        const bool counted_rows = COUNT ? (owned_rows && srow >= a.count_first && srow < a.count_end) : owned_rows;
+        bool owned = owned_rows, counted = counted_rows;
+        if constexpr (XR && COUNT) {                                      // ghost columns: kept and counted column ranges (even bounds: whole pairs)
+          const int gxo = x0 + fx - EX;                                   // the pair's storage column before any periodic wrap
+          owned = owned_rows && gxo >= a.keep_x0 && gxo < a.keep_x1;
+          counted = counted_rows && owned && gxo >= a.cx0 && gxo < a.cx1;
+        }
         bool accel_row_here = false;
         if (tile_accel) accel_row_here = on_accel_row(sr);
         acc[0] += finish_pair_lo<TERMS>(p, mbits, a.omega, tile_accel, (ksteps > 1 || a.accel_last) && accel_row_here, a.accel_w1, a.accel_w2, counted ? mbits : 3u, out, acc_lo[0]);
@@ -407,6 +431,9 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
   };
   if constexpr (PART == kPartGhost) {
     if (sy0 >= a.count_first && sy0 + TY <= a.count_end) k_substeps(std::false_type{});       // every row of the tile counts
+    else k_substeps(std::true_type{});
+  } else if constexpr (PART == kPartTile) {
+    if (sy0 >= a.count_first && sy0 + TY <= a.count_end && x0 >= a.cx0 && x0 + TX <= a.cx1) k_substeps(std::false_type{});   // ... and every column
     else k_substeps(std::true_type{});
   } else {
     k_substeps(std::false_type{});

@@ -22,11 +22,13 @@ struct P2PWindowHeader {                 // start of every rank's exported windo
   unsigned long long halo_parity[4];     // [2*dir + (epoch & 1)]: the pusher's grid parity for that epoch (lock-step check).  A pusher
                                          // may run ONE epoch ahead of the waiter, never two: a slot per epoch parity is not overwritten early
   unsigned long long reduce_flag[64];    // [r]: rank r's sums of reduce round N are in my slot r
-  unsigned long long halo_ack[2];        // [0]: my SOUTH neighbour has finished every launch that reads or writes its ghost rows of the grid the push of
+  unsigned long long halo_ack[4];        // [0]: my SOUTH neighbour has finished every launch that reads or writes its ghost rows of the grid the push of
                                          // this epoch writes: they may be written; [1]: NORTH.  The two grids
                                          // double-buffered the ghost rows only as long as every exchange was followed by ONE launch (rounds 1-3): a
                                          // group of two launches returns to the grid it started from, and the rows of epoch e+1 would land in the
-                                         // rows a neighbour still reads for epoch e.
+                                         // rows a neighbour still reads for epoch e.  Tile decomposition: [2] WEST, [3] EAST, for the ghost columns.
+  unsigned long long halo_flag_x[2];     // tile decomposition: [0]: epoch of the columns my WEST neighbour pushed into my west ghost columns; [1]: EAST
+  unsigned long long halo_parity_x[4];   // as halo_parity
 };
 constexpr size_t kP2PHeaderBytes = 4096;
 static_assert(sizeof(P2PWindowHeader) <= kP2PHeaderBytes, "window header");
@@ -107,6 +109,73 @@ __global__ void __launch_bounds__(256) lbm_p2p_push_kernel(const P2PPushArgs a, 
     }
     // my own push does not depend on this wait, so a ring of ranks that all sit here cannot dead-lock: every
     // rank's flags are raised by blocks that never wait for rows
+    if (blockIdx.x == 0 && a.wait_flags) p2p_wait_flags(a.wait_flags, a.wait_parity, 2, a.epoch, a.parity, a.timeout_ticks, a.err);
+  }
+}
+
+// Tile decomposition, first half of an exchange: my first k owned COLUMNS -> the west neighbour's east ghost columns, my last k -> the
+// east neighbour's west ghost columns, owned rows only, all 9 planes; flags; wait for both neighbours' columns.  The row push that
+// follows in the stream then sends whole storage rows — the ghost columns that have just arrived included — which carries the corner
+// blocks from the diagonal neighbours in two hops, with no third message.  Same structure as lbm_p2p_push_kernel (one release per block,
+// the last block raises the flags, block 0 waits); a message is k-float row segments, a chain of short strided accesses.
+struct P2PPushColsArgs {
+  const float* src;                      // my grid (plane 0, storage row 0)
+  size_t ps;
+  int src_w;                             // my storage row width
+  float* dst[2];                         // [0]: west neighbour's grid, plane 0, at (its first owned row, its first EAST ghost column); [1]: east neighbour's, at (first owned row, ghost_x - k)
+  size_t dst_ps[2];
+  int dst_w[2];                          // their storage row widths
+  int src_col[2];                        // my column where direction d's k columns start
+  int row0, nrows, k;                    // my first owned storage row, owned rows, columns per direction
+  unsigned long long* flag[2];           // [0]: west neighbour's halo_flag_x[1] (columns arrive from ITS east); [1]: east neighbour's halo_flag_x[0]
+  unsigned long long* parity_word[2];
+  unsigned long long epoch, parity;
+  unsigned int* done;
+  const unsigned long long* wait_flags;  // my halo_flag_x[2]
+  const unsigned long long* wait_parity; // my halo_parity_x[4]
+  long long timeout_ticks;
+  int* err;
+};
+
+template <typename V>      // V = f4, f2 or float: the widest access every row segment is aligned for
+__global__ void __launch_bounds__(256) lbm_p2p_push_cols_kernel(const P2PPushColsArgs a)
+{
+  constexpr int kPer = sizeof(V) / sizeof(float);
+  const int kv = a.k / kPer;                                   // vectors of one row segment
+  const int per_plane = a.nrows * kv;
+  const int total = per_plane * 18;
+  constexpr int kUnroll = 4;
+  for (int w0 = blockIdx.x * 256 + threadIdx.x; w0 < total; w0 += gridDim.x * 256 * kUnroll) {
+    V v[kUnroll];
+    float* q[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int w = w0 + u * gridDim.x * 256;
+      q[u] = nullptr;
+      if (w < total) {
+        const int seg = w / per_plane, i = w - seg * per_plane;
+        const int dir = seg / 9, plane = seg - dir * 9;
+        const int r = i / kv, j = i - r * kv;
+        v[u] = *reinterpret_cast<const V*>(a.src + plane * a.ps + static_cast<size_t>(a.row0 + r) * a.src_w + a.src_col[dir] + j * kPer);
+        q[u] = a.dst[dir] + plane * a.dst_ps[dir] + static_cast<size_t>(r) * a.dst_w[dir] + j * kPer;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)
+      if (q[u]) *reinterpret_cast<V*>(q[u]) = v[u];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);                   // system scope: this block's stores are out (see lbm_p2p_push_kernel)
+    const unsigned int prev = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.parity_word[d], a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int d = 0; d < 2; ++d) __hip_atomic_store(a.flag[d], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (blockIdx.x == 0 && a.wait_flags) p2p_wait_flags(a.wait_flags, a.wait_parity, 2, a.epoch, a.parity, a.timeout_ticks, a.err);
   }
 }

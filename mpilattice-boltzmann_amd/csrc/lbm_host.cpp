@@ -104,6 +104,23 @@ int lbm_decompose(int ny, int size, int* ny_local, int* displs)
   return 0;
 }
 
+// Column blocks of the tile (2-D) decomposition — the reference never built one (report.odt "MPI Design" discusses it), so there is no
+// rule to follow: whole x-PAIRS (the K-step kernels work on pairs of cells), nx / 2 pairs dealt as evenly as they go, the first ranks
+// taking the spare ones.
+int lbm_decompose_columns(int nx, int px, int* nx_local, int* displs)
+{
+  if (nx <= 0 || px <= 0 || !nx_local || !displs) { set_error("lbm_decompose_columns: bad argument"); return 1; }
+  if (nx % 2 != 0 || nx / 2 < px) { set_error("lbm_decompose_columns: the tile decomposition needs an even nx and at least one x-pair per rank"); return 1; }
+  const int pairs = nx / 2, each = pairs / px, spare = pairs % px;
+  int at = 0;
+  for (int r = 0; r < px; ++r) {
+    nx_local[r] = 2 * (each + (r < spare ? 1 : 0));
+    displs[r] = at;
+    at += nx_local[r];
+  }
+  return 0;
+}
+
 int lbm_plan_next(int K, int four_rows, int tail4, int left)
 {
   int k = left < K ? left : K;

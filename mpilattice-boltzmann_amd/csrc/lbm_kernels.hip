@@ -113,7 +113,12 @@ struct lbm_ctx {
   int accel_row = -1;
   int ghost = 0;             // storage rows below / above the owned rows (K-step kernels of a row-partitioned run)
   int group_max = 1;         // most launches a partitioned run makes per halo exchange (a group: their steps add up to <= ghost)
-  unsigned long long* ready_ptr[2] = {nullptr, nullptr};   // peer-to-peer loop: the next launch_multi says "ready for epoch ready_epoch" to the
+  // Tile (2-D) decomposition, lbm_create_tile: the rank owns the columns [x0, x0 + nxl) of its rows as well.  Its storage rows hold
+  // ghost_x ghost columns on each side and p.nx is THEIR width (nxl + 2 * ghost_x): kernels, masks and row arithmetic all work on
+  // storage rows; nx_global is the grid's.  Everywhere else ghost_x = 0, nxl = nx_global = p.nx.
+  int ghost_x = 0, x0 = 0, nxl = 0, nx_global = 0;
+  int tiles_px = 1, tiles_py = 1, tile_rx = 0, tile_ry = 0;
+  unsigned long long* ready_ptr[4] = {nullptr, nullptr, nullptr, nullptr};   // peer-to-peer loop: the next launch_multi says "ready for epoch ready_epoch" to the
   unsigned long long ready_epoch = 0;                       // neighbours (MultiArgs::ready) and waits for theirs; cleared by that launch
   const unsigned long long* ready_wait = nullptr;
   long long ready_timeout_ticks = 0;
@@ -274,6 +279,7 @@ void launch_multi_kgt(int blocks, hipStream_t s, const MultiArgs& a, int part)
   using G = MultiGeom<K, GEOM>;
   if (part == kPartGhost) lbm_multi_kernel<K, TERMS, GEOM, kPartGhost><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
   else if (part == kPartReady) lbm_multi_kernel<K, TERMS, GEOM, kPartReady><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
+  else if (part == kPartTile) lbm_multi_kernel<K, TERMS, GEOM, kPartTile><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
   else lbm_multi_kernel<K, TERMS, GEOM, kPartPlain><<<dim3(blocks + 1), dim3(G::LANES), G::lds_bytes, s>>>(a);
 }
 
@@ -284,12 +290,14 @@ hipError_t raise_multi_lds_limit()
 {
   using G = MultiGeom<K, GEOM>;
   if constexpr (G::lds_bytes > 65536) {
-    const void* fns[9] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartPlain>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartPlain>),
+    const void* fns[12] = {reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartPlain>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartPlain>),
                           reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartPlain>),
                           reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartGhost>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartGhost>),
                           reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartGhost>),
                           reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartReady>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartReady>),
-                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartReady>)};
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartReady>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsDouble, GEOM, kPartTile>), reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsFloat, GEOM, kPartTile>),
+                          reinterpret_cast<const void*>(&lbm_multi_kernel<K, kTermsCompensated, GEOM, kPartTile>)};
     for (const void* f : fns) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::lds_bytes));
       if (e != hipSuccess) return e;
@@ -346,6 +354,8 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx;
   a.row_first = c->ghost - ext; a.rows_compute = c->nyl + 2 * ext; a.rows_storage = c->nyl + 2 * c->ghost;
   a.count_first = c->ghost; a.count_end = c->ghost + c->nyl;
+  a.cx0 = c->ghost_x; a.cx1 = c->ghost_x + c->nxl;
+  a.keep_x0 = std::max(0, (c->ghost_x - ext) & ~1); a.keep_x1 = std::min(c->p.nx, (c->ghost_x + c->nxl + ext + 1) & ~1);
   a.y_periodic = c->self_periodic ? 1 : 0;
   a.y0_global = c->y0 - ext; a.ny_global = c->p.ny;          // global row of storage row row_first
   a.tiles_x = c->multi_tiles_x;
@@ -357,7 +367,8 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.prev_partials = c->partials[c->parity ^ 1];
   a.n_prev = fold ? c->n_prev : 0; a.n_prev_vecs = (fold && c->n_prev > 0) ? c->n_prev_vecs : 0;
   a.sums = c->sums; a.counter = c->counter;
-  a.ready[0] = c->ready_ptr[0]; a.ready[1] = c->ready_ptr[1]; a.ready_epoch = c->ready_epoch;
+  a.ready[0] = c->ready_ptr[0]; a.ready[1] = c->ready_ptr[1]; a.ready_x[0] = c->ready_ptr[2]; a.ready_x[1] = c->ready_ptr[3];
+  a.ready_epoch = c->ready_epoch;
   a.wait_ready = c->ready_epoch ? c->ready_wait : nullptr; a.timeout_ticks = c->ready_timeout_ticks; a.err = c->ready_err;
   c->ready_epoch = 0;
   const int blocks = n0 + n1;
@@ -366,7 +377,8 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
   // the instantiation (kernels/multi.h PART): ghost rows computed too -> the counted test; ready words to say -> the fold block carries them
-  const int part = ext > 0 ? kPartGhost : a.ready_epoch != 0ull ? kPartReady : kPartPlain;
+  // (a rank of the tile decomposition: ghost columns in every launch)
+  const int part = c->ghost_x > 0 ? kPartTile : ext > 0 ? kPartGhost : a.ready_epoch != 0ull ? kPartReady : kPartPlain;
   switch (ksteps) {                                            // <= multi_K, or 4 in the tail of a K = 3 run (lbm_run)
     case 1: launch_multi_k<1>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
     case 2: launch_multi_k<2>(blocks, s, a, c->multi_terms, c->multi_geom, part); break;
@@ -457,8 +469,8 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
   if (c->accel_row >= 0 && n_steps > 0) {
     // accelerate_flow of step 0 (d2q9-bgk.c:345-348); later steps get it from the kernel epilogue
     const int nx = c->p.nx;
-    hipLaunchKernelGGL(lbm_accelerate_kernel, dim3((nx + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps,
-                       c->mask, nx, c->ghost + c->accel_row, c->accel_w1, c->accel_w2);
+    hipLaunchKernelGGL(lbm_accelerate_kernel, dim3((c->nxl + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps,
+                       c->mask, nx, c->ghost + c->accel_row, c->accel_w1, c->accel_w2, c->ghost_x, c->nxl);
     HIP_TRY(hipGetLastError());
   }
   c->ev_valid = false;
@@ -668,9 +680,11 @@ static void pack_obstacle_bits(std::vector<uint32_t>& bits, int rows, int nx, Ro
 // ((ny_local + 2*forced_k)*nx: the rows around the partition only, lbm_create_rank); both null = no ghost
 // rows possible.  forced_k < 0: K-step mode and K decided from this partition's own shape
 // (lbm_create_global); >= 0: decided by the caller for the whole run (lbm_rank_layout).
+struct TileSpec { int px, py, rx, ry, x0, nxl, ghost_x, nx_global; };    // lbm_create_tile: `p->nx` is then the storage row width nxl + 2 ghost_x
+
 static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows,
                        const int* obstacles_global, const int* obstacles_window, int forced_k, int forced_ghost, int y0, int ny_local,
-                       int device, unsigned flags)
+                       int device, unsigned flags, const TileSpec* tile = nullptr)
 {
   if (!out || !p || !obstacles_rows) { lbm_internal::set_error("lbm_create: null argument"); return 1; }
   *out = nullptr;
@@ -694,6 +708,11 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->free_cells = free_cells;
   c->free_cells_inv = 1.0f / free_cells;                                    // d2q9-bgk.c:950
   c->y0 = y0; c->nyl = ny_local; c->device = device; c->flags = flags;
+  c->nxl = c->nx_global = p->nx;
+  if (tile) {
+    c->ghost_x = tile->ghost_x; c->x0 = tile->x0; c->nxl = tile->nxl; c->nx_global = tile->nx_global;
+    c->tiles_px = tile->px; c->tiles_py = tile->py; c->tile_rx = tile->rx; c->tile_ry = tile->ry;
+  }
   c->self_periodic = self_periodic;
   c->fast_avvels = (flags & LBM_FLAG_FAST_AVVELS) != 0;
   c->multi_terms = c->fast_avvels ? kTermsFloat : (flags & LBM_FLAG_EXACT_AVVELS) ? kTermsDouble : kTermsCompensated;
@@ -891,6 +910,11 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   return 0;
 }
 
+// The owned cells of a context as the I/O entry points see them: all columns of the owned rows, or — a rank of the tile
+// decomposition — the columns [ghost_x, ghost_x + nxl) of its storage rows.
+static ColWindow col_window(const lbm_ctx* c) { return ColWindow{static_cast<unsigned>(c->p.nx), static_cast<unsigned>(c->ghost_x), static_cast<unsigned>(c->nxl)}; }
+static size_t owned_cells(const lbm_ctx* c) { return static_cast<size_t>(c->nxl) * c->nyl; }
+
 extern "C" {
 
 int lbm_create(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows, int y0,
@@ -934,6 +958,64 @@ int lbm_create_rank(lbm_ctx** out, const lbm_params* p, int free_cells, const in
   if (lbm_rank_layout(p, nranks, rank, flags, &lay)) return 1;
   const int* rows = obstacle_window + static_cast<size_t>(lay.ghost) * p->nx;          // the owned rows inside the window
   return create_impl(out, p, free_cells, rows, nullptr, obstacle_window, lay.macro_k, lay.ghost, lay.y0, lay.ny_local, device, flags);
+}
+
+// ---- tile (2-D) decomposition: px x py ranks, rank = ry * px + rx ------------------------------------------------------------
+// Rows by the reference's rule over py (d2q9-bgk.c:834-862), columns by lbm_decompose_columns over px.  Always K-step mode: ghost rows
+// as a row partition of the same cells would keep, ghost columns the same number rounded up to even (x-pairs).
+int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned flags, lbm_tile_layout* out)
+{
+  if (!p || !out || px < 1 || py < 1 || rank < 0 || rank >= px * py) { lbm_internal::set_error("lbm_tile_layout_of: bad argument"); return 1; }
+  if (p->nx < 1 || p->ny < 3 || p->ny < py) { lbm_internal::set_error("lbm_tile_layout_of: grid too small for this many ranks"); return 1; }
+  std::vector<int> nyl(py), ydis(py), nxl(px), xdis(px);
+  if (lbm_decompose(p->ny, py, nyl.data(), ydis.data())) return 1;
+  if (lbm_decompose_columns(p->nx, px, nxl.data(), xdis.data())) return 1;
+  const int rlo = *std::min_element(nyl.begin(), nyl.end()), rhi = *std::max_element(nyl.begin(), nyl.end());
+  const int clo = *std::min_element(nxl.begin(), nxl.end()), chi = *std::max_element(nxl.begin(), nxl.end());
+  if (rlo < 1) { lbm_internal::set_error("lbm_tile_layout_of: a rank would own no rows"); return 1; }
+  std::memset(out, 0, sizeof *out);
+  out->px = px; out->py = py; out->rx = rank % px; out->ry = rank / px;
+  out->x0 = xdis[out->rx]; out->nx_local = nxl[out->rx];
+  out->y0 = ydis[out->ry]; out->ny_local = nyl[out->ry];
+  const int k = macro_k_for(static_cast<size_t>(chi) * rhi);
+  const int ghost = macro_ghost_for(k, chi, rlo, rhi);
+  const int ghost_x = (ghost + 1) & ~1;
+  // every rank's storage rows (owned + ghost columns) must be ones the K-step kernels take, and its own columns at least the ghost
+  // columns its neighbours need from it
+  lbm_params narrow = *p, wide = *p;
+  narrow.nx = clo + 2 * ghost_x; wide.nx = chi + 2 * ghost_x;
+  if (k <= 0 || !macro_eligible(&narrow, rlo, flags) || !macro_eligible(&wide, rhi, flags) || !macro_eligible(&narrow, rhi, flags) || !macro_eligible(&wide, rlo, flags) ||
+      clo < ghost_x || rlo < ghost) {
+    lbm_internal::set_error("lbm_tile_layout_of: the tile decomposition runs in K-step mode only: every rank needs >= 32 rows, an even number of columns with "
+                            "at least 128 storage columns (owned + ghost) and LBM_FLAG_ONE_STEP clear — use the row decomposition (lbm_rank_layout)");
+    return 1;
+  }
+  out->macro_k = k; out->ghost = ghost; out->ghost_x = ghost_x;
+  out->group = macro_group_for(k, ghost);
+  return 0;
+}
+
+int lbm_create_tile(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacle_window, int px, int py, int rank, int device, unsigned flags)
+{
+  lbm_tile_layout lay;
+  if (!obstacle_window) { lbm_internal::set_error("lbm_create_tile: null argument"); return 1; }
+  if (lbm_tile_layout_of(p, px, py, rank, flags, &lay)) return 1;
+  lbm_params local = *p;
+  local.nx = lay.nx_local + 2 * lay.ghost_x;                                           // the storage row: what every kernel works on
+  const TileSpec tile{px, py, lay.rx, lay.ry, lay.x0, lay.nx_local, lay.ghost_x, p->nx};
+  const int* rows = obstacle_window + static_cast<size_t>(lay.ghost) * local.nx;      // the owned rows inside the window
+  return create_impl(out, &local, free_cells, rows, nullptr, obstacle_window, lay.macro_k, lay.ghost, lay.y0, lay.ny_local, device,
+                     flags | LBM_FLAG_FORCE_HALO, &tile);
+}
+
+int lbm_tile_info(const lbm_ctx* c, lbm_tile_layout* out)
+{
+  if (!c || !out) { lbm_internal::set_error("lbm_tile_info: null argument"); return 1; }
+  std::memset(out, 0, sizeof *out);
+  out->px = c->tiles_px; out->py = c->tiles_py; out->rx = c->tile_rx; out->ry = c->tile_ry;
+  out->x0 = c->x0; out->nx_local = c->nxl; out->y0 = c->y0; out->ny_local = c->nyl;
+  out->macro_k = c->ghost > 0 ? c->multi_K : 0; out->ghost = c->ghost; out->ghost_x = c->ghost_x; out->group = c->group_max;
+  return 0;
 }
 
 int lbm_destroy(lbm_ctx* c)
@@ -1063,11 +1145,11 @@ int lbm_get_cells(lbm_ctx* c, float* cells_aos)
   if (!c || !cells_aos) { lbm_internal::set_error("lbm_get_cells: null argument"); return 1; }
   HIP_TRY(hipSetDevice(c->device));
   float* tmp = nullptr;
-  const size_t n = c->ncells * 9;
+  const size_t n = owned_cells(c) * 9;
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * n));
   const int blocks = static_cast<int>((n + 255) / 256);
   hipLaunchKernelGGL(lbm_soa_to_aos_kernel, dim3(blocks), dim3(256), 0, c->stream,
-                     c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, tmp, c->ps, c->ncells);
+                     c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, tmp, c->ps, owned_cells(c), col_window(c));
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(cells_aos, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1081,13 +1163,13 @@ int lbm_set_cells(lbm_ctx* c, const float* cells_aos)
   if (!c || !cells_aos) { lbm_internal::set_error("lbm_set_cells: null argument"); return 1; }
   HIP_TRY(hipSetDevice(c->device));
   float* tmp = nullptr;
-  const size_t n = c->ncells * 9;
+  const size_t n = owned_cells(c) * 9;
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * n));
   hipError_t e = hipMemcpyAsync(tmp, cells_aos, sizeof(float) * n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     const int blocks = static_cast<int>((n + 255) / 256);
     hipLaunchKernelGGL(lbm_aos_to_soa_kernel, dim3(blocks), dim3(256), 0, c->stream, tmp,
-                       c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps, c->ncells);
+                       c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps, owned_cells(c), col_window(c));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1101,15 +1183,17 @@ int lbm_get_observables(lbm_ctx* c, float* obs)
   if (!c || !obs) { lbm_internal::set_error("lbm_get_observables: null argument"); return 1; }
   HIP_TRY(hipSetDevice(c->device));
   // row blocks of at most 16 M cells through a 256 MB device buffer: no second copy of the state
-  const size_t chunk = std::min<size_t>(c->ncells, size_t(16) << 20);
+  // (whole rows per block, so that a block of a tile rank's column window starts on a row)
+  const size_t total = owned_cells(c);
+  const size_t chunk = std::min<size_t>(total, std::max<size_t>(1, (size_t(16) << 20) / c->nxl) * c->nxl);
   float* tmp = nullptr;
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * 4 * chunk));
   hipError_t e = hipSuccess;
   const float* owned = c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx;
-  for (size_t c0 = 0; c0 < c->ncells && e == hipSuccess; c0 += chunk) {
-    const size_t n = std::min(chunk, c->ncells - c0);
+  for (size_t c0 = 0; c0 < total && e == hipSuccess; c0 += chunk) {
+    const size_t n = std::min(chunk, total - c0);
     hipLaunchKernelGGL(lbm_observables_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                       owned + c0, c->ps, n, tmp);
+                       owned + c0 / c->nxl * c->p.nx, c->ps, n, tmp, col_window(c));
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(obs + 4 * c0, tmp, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1127,13 +1211,13 @@ int lbm_state_checksum(lbm_ctx* c, int y_begin, int y_end, unsigned long long* d
   unsigned long long* dev = nullptr;
   HIP_TRY(hipMalloc(&dev, sizeof *dev));
   const size_t nx = static_cast<size_t>(c->p.nx);
-  const size_t n = static_cast<size_t>(y_end - y_begin) * nx;
+  const size_t n = static_cast<size_t>(y_end - y_begin) * c->nxl;
   const size_t c0 = (static_cast<size_t>(c->ghost) + static_cast<size_t>(y_begin - c->y0)) * nx;
   hipError_t e = hipMemsetAsync(dev, 0, sizeof *dev, c->stream);
   if (e == hipSuccess && n > 0) {
     const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 4096));
     hipLaunchKernelGGL(lbm_checksum_kernel, dim3(blocks), dim3(kBlock), 0, c->stream, c->grid[c->cur] + c0, c->ps, n,
-                       static_cast<unsigned long long>(y_begin) * nx, dev);
+                       static_cast<unsigned long long>(y_begin) * c->nx_global + c->x0, dev, col_window(c), static_cast<unsigned>(c->nx_global));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(digest, dev, sizeof *dev, hipMemcpyDeviceToHost, c->stream);
@@ -1147,14 +1231,14 @@ int lbm_av_velocity_sum(lbm_ctx* c, double* tot_u)
 {
   if (!c || !tot_u) { lbm_internal::set_error("lbm_av_velocity_sum: null argument"); return 1; }
   HIP_TRY(hipSetDevice(c->device));
-  const int blocks = static_cast<int>(std::min<size_t>((c->ncells + kBlock - 1) / kBlock, 1024));
+  const int blocks = static_cast<int>(std::min<size_t>((owned_cells(c) + kBlock - 1) / kBlock, 1024));
   double* part = nullptr;
   HIP_TRY(hipMalloc(&part, sizeof(double) * blocks));
   // owned rows only; in K-step mode they start ghost rows in: bit offset ghost*nx of the bitfield (any value:
   // nx = 130, K = 3 gives 390)
   hipLaunchKernelGGL(lbm_av_velocity_kernel, dim3(blocks), dim3(kBlock), 0, c->stream,
                      c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps,
-                     c->mask, static_cast<size_t>(c->ghost) * c->p.nx, c->ncells, part);
+                     c->mask, static_cast<size_t>(c->ghost) * c->p.nx, owned_cells(c), part, col_window(c));
   std::vector<double> host(blocks);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, sizeof(double) * blocks, hipMemcpyDeviceToHost, c->stream);
@@ -1318,6 +1402,7 @@ int lbm_macro_unpack(lbm_ctx* c, void* stream)
 int lbm_macro_prepare(lbm_ctx* c, int n_steps, void* stream)
 {
   if (!c || n_steps < 0 || c->ghost == 0) { lbm_internal::set_error("lbm_macro_prepare: not a K-step context"); return 1; }
+  if (c->ghost_x > 0) { lbm_internal::set_error("lbm_macro_prepare: ranks of the tile decomposition are stepped by the peer-to-peer loop (lbm_p2p_run) only"); return 1; }
   HIP_TRY(hipSetDevice(c->device));
   return begin_run(c, n_steps, pick_stream(c, stream));
 }

@@ -42,7 +42,8 @@ constexpr uint32_t kP2PMagic = 0x4C424D50u;   // "LBMP"
 struct P2PBlob {                       // what every rank tells every other rank (POD, <= LBM_P2P_HANDLE_BYTES)
   uint32_t magic, version;
   int32_t pid, device, nranks, rank;
-  int32_t nx, ny, y0, nyl, ghost, K, cur, ipc_ok, group;
+  int32_t nx, ny, y0, nyl, ghost, K, cur, ipc_ok, group;      // nx: the GLOBAL grid width
+  int32_t w, x0, nxl, ghost_x, px, py;                         // storage row width; tile decomposition: the rank's columns and the rank grid (1 x nranks otherwise)
   uint64_t ps, window_bytes, reduce_cap;
   uint64_t grid_ptr[2], window_ptr;    // raw device pointers: valid inside the exporting process
   hipIpcMemHandle_t grid_h[2], window_h;
@@ -63,6 +64,8 @@ struct lbm_p2p {
   lbm_ctx* ctx = nullptr;
   int device = 0;                      // ctx's device, kept here: lbm_p2p_destroy must not depend on the context still existing
   int nranks = 1, rank = 0, south = 0, north = 0;
+  bool tiles = false;                  // the context is a rank of the tile decomposition (lbm_create_tile): ghost columns, west / east neighbours
+  int west = 0, east = 0;
   hipStream_t compute = nullptr, edge = nullptr;
   hipEvent_t edge_done = nullptr, interior_done = nullptr;
   bool edge_stream = true;             // edge rows on their own stream beside the interior launch
@@ -154,6 +157,10 @@ void p2p_say_ready(lbm_p2p* t, unsigned long long epoch)
   lbm_ctx* c = t->ctx;
   c->ready_ptr[0] = &header_of(t->peers[t->south].window)->halo_ack[1];
   c->ready_ptr[1] = &header_of(t->peers[t->north].window)->halo_ack[0];
+  if (t->tiles) {                      // ... and the west neighbour's EAST one, the east neighbour's WEST one (ghost columns)
+    c->ready_ptr[2] = &header_of(t->peers[t->west].window)->halo_ack[3];
+    c->ready_ptr[3] = &header_of(t->peers[t->east].window)->halo_ack[2];
+  }
   c->ready_epoch = epoch;
   c->ready_wait = header_of(t->window)->halo_ack;
   c->ready_timeout_ticks = t->timeout_ticks;
@@ -163,9 +170,51 @@ void p2p_say_ready(lbm_p2p* t, unsigned long long epoch)
 // (After a group of SEVERAL launches the push needs the neighbours' word that their ghost rows may be written — see
 // P2PWindowHeader::halo_ack; it is said and awaited by the group's last launch, p2p_say_ready.  Never needed for the first push of a
 // run: every rank's launches of the run before are complete when any rank leaves its reduction.)
+// Tile decomposition: the k ghost columns on each side first (owned rows; push + flags + wait), so that the row push below sends them along.
+int p2p_push_cols(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s)
+{
+  lbm_ctx* c = t->ctx;
+  const P2PPeer& pw = t->peers[t->west];
+  const P2PPeer& pe = t->peers[t->east];
+  const int g = c->cur, gx = c->ghost_x;
+  P2PPushColsArgs a{};
+  a.src = c->grid[g]; a.ps = c->ps; a.src_w = c->p.nx;
+  // west neighbour: the first k of its EAST ghost columns; east neighbour: the last k of its west ghost columns (its rows are mine:
+  // the same y0, the same ghost rows)
+  a.dst[0] = pw.grid_alloc[g] + 64 + static_cast<size_t>(pw.blob.ghost) * pw.blob.w + (pw.blob.ghost_x + pw.blob.nxl);
+  a.dst[1] = pe.grid_alloc[g] + 64 + static_cast<size_t>(pe.blob.ghost) * pe.blob.w + (pe.blob.ghost_x - k);
+  a.dst_ps[0] = pw.blob.ps; a.dst_ps[1] = pe.blob.ps;
+  a.dst_w[0] = pw.blob.w; a.dst_w[1] = pe.blob.w;
+  a.src_col[0] = gx;                    // my first k owned columns
+  a.src_col[1] = gx + c->nxl - k;       // my last k owned columns
+  a.row0 = c->ghost; a.nrows = c->nyl; a.k = k;
+  a.flag[0] = &header_of(pw.window)->halo_flag_x[1];      // my columns arrive from the west neighbour's EAST
+  a.flag[1] = &header_of(pe.window)->halo_flag_x[0];
+  a.parity_word[0] = &header_of(pw.window)->halo_parity_x[2 * 1 + (epoch & 1ull)];
+  a.parity_word[1] = &header_of(pe.window)->halo_parity_x[2 * 0 + (epoch & 1ull)];
+  a.epoch = epoch; a.parity = static_cast<unsigned long long>(g);
+  a.done = t->done;
+  a.wait_flags = header_of(t->window)->halo_flag_x;
+  a.wait_parity = header_of(t->window)->halo_parity_x;
+  a.timeout_ticks = t->timeout_ticks; a.err = t->err;
+  auto all_mult = [&](int m) {
+    return k % m == 0 && gx % m == 0 && c->nxl % m == 0 && c->p.nx % m == 0 && c->ps % m == 0 && pw.blob.w % m == 0 && pe.blob.w % m == 0 &&
+           pw.blob.ps % m == 0 && pe.blob.ps % m == 0 && pw.blob.nxl % m == 0 && pw.blob.ghost_x % m == 0 && pe.blob.ghost_x % m == 0;
+  };
+  const int per = all_mult(4) ? 4 : all_mult(2) ? 2 : 1;
+  const int work = 18 * c->nyl * (k / per);
+  const dim3 grid(std::max(1, std::min(kP2PPushBlocks, (work + 1023) / 1024)));
+  if (per == 4) hipLaunchKernelGGL(lbm_p2p_push_cols_kernel<f4>, grid, dim3(256), 0, s, a);
+  else if (per == 2) hipLaunchKernelGGL(lbm_p2p_push_cols_kernel<f2>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lbm_p2p_push_cols_kernel<float>, grid, dim3(256), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool exposed = false)
 {
   lbm_ctx* c = t->ctx;
+  if (t->tiles && p2p_push_cols(t, epoch, k, s)) return 1;
   const P2PPeer& ps = t->peers[t->south];
   const P2PPeer& pn = t->peers[t->north];
   const int nx = c->p.nx, g = c->cur;
@@ -323,13 +372,23 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   t->rank = rank;
   t->south = (rank + nranks - 1) % nranks;   // `top`    d2q9-bgk.c:245-246
   t->north = (rank + 1) % nranks;            // `bottom` d2q9-bgk.c:247
+  if (ctx->ghost_x > 0) {                    // tile decomposition: rank = ry * px + rx, periodic in both directions
+    const int px = ctx->tiles_px, py = ctx->tiles_py, rx = ctx->tile_rx, ry = ctx->tile_ry;
+    if (nranks != px * py || rank != ry * px + rx) { lbm_internal::set_error("lbm_p2p_create: the context is rank " + std::to_string(ry * px + rx) + " of " + std::to_string(px * py) + " tiles"); delete t; return 1; }
+    t->tiles = true;
+    t->south = ((ry + py - 1) % py) * px + rx;
+    t->north = ((ry + 1) % py) * px + rx;
+    t->west = ry * px + (rx + px - 1) % px;
+    t->east = ry * px + (rx + 1) % px;
+  }
   t->compute = ctx->stream;
   t->peers.resize(nranks);
   t->timeout_ticks = static_cast<long long>(tune_env("LBM_P2P_TIMEOUT_MS", 30000)) * 100000LL;   // wall_clock64: 100 MHz
   // default by size, as the RCCL loop: an own stream for the edge rows pays once the interior launch is long
   // enough to cover two cross-queue waits
   t->edge_stream = ctx->ncells >= (size_t(1) << 21);
-  if (const char* sched = std::getenv("LBM_P2P_SCHEDULE")) {
+  if (t->tiles) t->edge_stream = false;      // every tile of a launch holds ghost columns: nothing to run beside the exchange
+  else if (const char* sched = std::getenv("LBM_P2P_SCHEDULE")) {
     if (std::string(sched) == "serial") t->edge_stream = false;
     if (std::string(sched) == "edge") t->edge_stream = true;
   }
@@ -395,7 +454,8 @@ int lbm_p2p_handle(lbm_p2p* t, void* blob_out)
   P2PBlob b{};
   b.magic = kP2PMagic; b.version = LBM_ABI_VERSION;
   b.pid = static_cast<int32_t>(getpid()); b.device = c->device; b.nranks = t->nranks; b.rank = t->rank;
-  b.nx = c->p.nx; b.ny = c->p.ny; b.y0 = c->y0; b.nyl = c->nyl; b.ghost = c->ghost; b.K = c->multi_K; b.cur = c->cur; b.group = c->group_max;
+  b.nx = c->nx_global; b.ny = c->p.ny; b.y0 = c->y0; b.nyl = c->nyl; b.ghost = c->ghost; b.K = c->multi_K; b.cur = c->cur; b.group = c->group_max;
+  b.w = c->p.nx; b.x0 = c->x0; b.nxl = c->nxl; b.ghost_x = c->ghost_x; b.px = t->tiles ? c->tiles_px : 1; b.py = t->tiles ? c->tiles_py : t->nranks;
   b.ps = c->ps; b.window_bytes = t->window_bytes; b.reduce_cap = t->reduce_cap;
   // IPC handles serve peers in OTHER processes; contexts of one process use the raw pointers, so a
   // runtime that cannot export a handle only rules out the multi-process form (checked at connect)
@@ -424,7 +484,7 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
   const int32_t me = static_cast<int32_t>(getpid());
   char host[64] = {0};
   (void)gethostname(host, sizeof host - 1);
-  int rows = 0;
+  long long cells = 0;
   for (int r = 0; r < t->nranks; ++r) {
     P2PPeer& p = t->peers[r];
     std::memcpy(&p.blob, base + static_cast<size_t>(r) * LBM_P2P_HANDLE_BYTES, sizeof(P2PBlob));
@@ -435,7 +495,8 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
       lbm_internal::set_error("lbm_p2p_connect: handle " + std::to_string(r) + " is not rank " + std::to_string(r) + " of this run");
       return 1;
     }
-    if (b.nx != c->p.nx || b.ny != c->p.ny || b.K != c->multi_K || b.ghost != c->ghost || b.group != c->group_max || b.cur != c->cur || b.reduce_cap != t->reduce_cap) {
+    if (b.nx != c->nx_global || b.ny != c->p.ny || b.K != c->multi_K || b.ghost != c->ghost || b.group != c->group_max || b.cur != c->cur || b.reduce_cap != t->reduce_cap ||
+        b.ghost_x != c->ghost_x || b.px != (t->tiles ? c->tiles_px : 1) || b.py != (t->tiles ? c->tiles_py : t->nranks)) {
       lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " runs a different layout (nx " + std::to_string(b.nx) + ", ny " +
                               std::to_string(b.ny) + ", K " + std::to_string(b.K) + ", " + std::to_string(b.ghost) + " ghost rows, " + std::to_string(b.group) +
                               " launches per exchange) than rank " + std::to_string(t->rank) + " (K " + std::to_string(c->multi_K) + ", " + std::to_string(c->ghost) +
@@ -446,13 +507,13 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
       lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " runs on another host; peer-to-peer halos need one node");
       return 1;
     }
-    rows += b.nyl;
+    cells += static_cast<long long>(b.nyl) * b.nxl;
   }
-  if (rows != c->p.ny) { lbm_internal::set_error("lbm_p2p_connect: the ranks' rows do not add up to ny"); return 1; }
+  if (cells != static_cast<long long>(c->p.ny) * c->nx_global) { lbm_internal::set_error("lbm_p2p_connect: the ranks' blocks do not add up to the grid"); return 1; }
   for (int r = 0; r < t->nranks; ++r) {
     P2PPeer& p = t->peers[r];
     const P2PBlob& b = p.blob;
-    const bool neighbour = r == t->south || r == t->north;
+    const bool neighbour = r == t->south || r == t->north || (t->tiles && (r == t->west || r == t->east));
     if (r == t->rank) {                                        // myself: a 1-rank ring, or my own reduce slot
       for (int g = 0; g < 2; ++g) p.grid_alloc[g] = c->grid_alloc[g];
       p.window = t->window;
@@ -742,8 +803,10 @@ int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)
     std::snprintf(text, len, "window %s; neighbours %s; one-step mode", t->window_kind, reach);
     return 0;
   }
-  std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d; ghost rows %d; launches per exchange %d", t->window_kind, reach,
-                t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K, t->ctx->ghost, t->ctx->group_max);
+  int n = std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d; ghost rows %d; launches per exchange %d", t->window_kind, reach,
+                        t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K, t->ctx->ghost, t->ctx->group_max);
+  if (t->tiles && n > 0 && static_cast<size_t>(n) < len)
+    std::snprintf(text + n, len - n, "; tiles %d x %d; ghost columns %d", t->ctx->tiles_px, t->ctx->tiles_py, t->ctx->ghost_x);
   return 0;
 }
 

@@ -80,6 +80,13 @@ int lbm_comm_create(lbm_comm** out, lbm_ctx* ctx, const char id[LBM_COMM_ID_BYTE
 {
   if (!out || !ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) { lbm_internal::set_error("lbm_comm_create: bad argument"); return 1; }
   *out = nullptr;
+  {
+    lbm_tile_layout tile;
+    if (lbm_tile_info(ctx, &tile) == 0 && tile.ghost_x > 0) {
+      lbm_internal::set_error("lbm_comm_create: the context is a rank of the tile decomposition, which the peer-to-peer loop steps (lbm_p2p_run); the RCCL loop takes row partitions");
+      return 1;
+    }
+  }
   lbm_comm* c = new lbm_comm();
   c->ctx = ctx;
   c->nranks = nranks;

@@ -103,13 +103,27 @@ def plan_groups(K: int, ghost: int, group_max: int, n_steps: int) -> list[list[i
     return out
 
 
+def tile_layout(params: Params, px: int, py: int, rank: int, flags: int = 0) -> dict:
+    """`lbm_tile_layout_of`: the block of `rank` = ry * px + rx in a px x py tile (2-D) decomposition — rows by the reference's
+    rule over py, columns in whole x-pairs over px — and the K-step layout of the whole run (ghost rows, ghost columns)."""
+    lib = _capi.load_library()
+    lay = _capi.CTileLayout()
+    cp = _cparams(params)
+    check(lib.lbm_tile_layout_of(C.byref(cp), px, py, rank, flags, C.byref(lay)))
+    return {name: int(getattr(lay, name)) for name, _ in _capi.CTileLayout._fields_}
+
+
 def obstacle_window(obstacles: np.ndarray, layout: dict) -> np.ndarray:
-    """The rows of the global map one rank needs: its owned rows plus `ghost` rows below and above,
+    """The part of the global map one rank needs: its owned rows plus `ghost` rows below and above,
     wrapping periodically — what the root hands each rank instead of the reference's `MPI_Scatterv` of
-    the owned rows alone (`d2q9-bgk.c:968-970`)."""
-    ny = obstacles.shape[0]
+    the owned rows alone (`d2q9-bgk.c:968-970`).  A rank of the tile decomposition (`tile_layout`) gets
+    its columns plus `ghost_x` on each side of those rows."""
+    ny, nx = obstacles.shape
     rows = np.arange(layout["y0"] - layout["ghost"], layout["y0"] + layout["ny_local"] + layout["ghost"]) % ny
-    return np.ascontiguousarray(obstacles[rows], dtype=np.int32)
+    if "ghost_x" not in layout:
+        return np.ascontiguousarray(obstacles[rows], dtype=np.int32)
+    cols = np.arange(layout["x0"] - layout["ghost_x"], layout["x0"] + layout["nx_local"] + layout["ghost_x"]) % nx
+    return np.ascontiguousarray(obstacles[np.ix_(rows, cols)], dtype=np.int32)
 
 
 def av_velocity_host(params: Params, cells: np.ndarray, obstacles: np.ndarray) -> float:
@@ -177,13 +191,29 @@ class Partition:
 
     def __init__(self, params: Params, free_cells: int, obstacles_rows: np.ndarray, y0: int = 0,
                  device: int = 0, flags: int = 0, obstacles_global: Optional[np.ndarray] = None,
-                 rank_of: Optional[tuple[int, int]] = None):
+                 rank_of: Optional[tuple[int, int]] = None, tile_of: Optional[tuple[int, int, int]] = None):
         """obstacles_global: the whole (ny, nx) map; when given (`lbm_create_global`) an eligible
         row partition runs in K-step mode (`macro_steps` > 0) and obstacles_rows is ignored.
         rank_of = (rank, nranks): obstacles_rows is this rank's obstacle WINDOW (`obstacle_window`) and the
-        context comes from `lbm_create_rank`, whose stepping mode is the same on every rank of the run."""
+        context comes from `lbm_create_rank`, whose stepping mode is the same on every rank of the run.
+        tile_of = (rank, px, py): a rank of the tile decomposition (`lbm_create_tile`); obstacles_rows is its
+        window of `tile_layout` (rows and columns with their ghosts)."""
         self._lib = _capi.load_library()
         obst = np.ascontiguousarray(obstacles_rows, dtype=np.int32)
+        self.x0, self.nx_local = 0, params.nx
+        if tile_of is not None:
+            rank, px, py = tile_of
+            lay = tile_layout(params, px, py, rank, flags)
+            if obst.shape != (lay["ny_local"] + 2 * lay["ghost"], lay["nx_local"] + 2 * lay["ghost_x"]):
+                raise ValueError("obstacles_rows must be the rank's window: (ny_local + 2*ghost, nx_local + 2*ghost_x)")
+            self.params, self.free_cells, self.device = params, free_cells, device
+            self.y0, self.ny_local, self.x0, self.nx_local = lay["y0"], lay["ny_local"], lay["x0"], lay["nx_local"]
+            self.free_cells_inv = np.float32(1.0) / np.float32(free_cells)
+            self._ctx = C.c_void_p()
+            cp = _cparams(params)
+            check(self._lib.lbm_create_tile(C.byref(self._ctx), C.byref(cp), free_cells, _capi.as_int_ptr(obst), px, py, rank, device, flags))
+            self._halo_tensors = None
+            return
         if obst.ndim != 2 or obst.shape[1] != params.nx:
             raise ValueError("obstacles_rows must be (ny_local, nx)")
         self.params, self.free_cells, self.y0, self.ny_local, self.device = params, free_cells, y0, obst.shape[0], device
@@ -267,20 +297,26 @@ class Partition:
         return av[:n_steps]
 
     # -- state --
+    def tile_info(self) -> dict:
+        """`lbm_tile_info`: the block this context owns and its K-step layout."""
+        lay = _capi.CTileLayout()
+        check(self._lib.lbm_tile_info(self._ctx, C.byref(lay)))
+        return {name: int(getattr(lay, name)) for name, _ in _capi.CTileLayout._fields_}
+
     def get_cells(self) -> np.ndarray:
-        cells = np.empty((self.ny_local, self.params.nx, _capi.NSPEEDS), dtype=np.float32)
+        cells = np.empty((self.ny_local, self.nx_local, _capi.NSPEEDS), dtype=np.float32)
         check(self._lib.lbm_get_cells(self._ctx, _capi.as_float_ptr(cells)))
         return cells
 
     def set_cells(self, cells: np.ndarray) -> None:
         cells = np.ascontiguousarray(cells, dtype=np.float32)
-        if cells.shape != (self.ny_local, self.params.nx, _capi.NSPEEDS):
-            raise ValueError("cells must be (ny_local, nx, 9)")
+        if cells.shape != (self.ny_local, self.nx_local, _capi.NSPEEDS):
+            raise ValueError("cells must be (ny_local, nx_local, 9)")
         check(self._lib.lbm_set_cells(self._ctx, _capi.as_float_ptr(cells)))
 
     def get_observables(self) -> np.ndarray:
         """(ny_local, nx, 4) float32: u_x, u_y, u, pressure per cell, computed on the device (`d2q9-bgk.c:1084-1111`)."""
-        obs = np.empty((self.ny_local, self.params.nx, 4), dtype=np.float32)
+        obs = np.empty((self.ny_local, self.nx_local, 4), dtype=np.float32)
         check(self._lib.lbm_get_observables(self._ctx, _capi.as_float_ptr(obs)))
         return obs
 
@@ -696,10 +732,12 @@ class Simulation:
 
     def __init__(self, params: Params, obstacles: Optional[np.ndarray], *, device: int = 0, flags: int = 0,
                  distributed: bool = False, group=None, exchange: str = "auto", strict: bool = False,
-                 free_cells: Optional[int] = None, step_allreduce: bool = False):
+                 free_cells: Optional[int] = None, step_allreduce: bool = False, rank_grid: Optional[tuple[int, int]] = None):
         """obstacles: the whole (ny, nx) map — or, in a distributed run, None on every rank but 0: rank 0 then
         hands each rank its window of rows (the reference's `MPI_Scatterv`, `d2q9-bgk.c:968-970`) and the
-        free-cell count (`MPI_Bcast`, `:966`)."""
+        free-cell count (`MPI_Bcast`, `:966`).
+        rank_grid = (px, py): the tile (2-D) decomposition over px x py = size ranks (`tile_layout`) instead of the
+        reference's row blocks — peer-to-peer loop only; (1, 1) is a one-rank ring that exchanges with itself."""
         if exchange not in EXCHANGES:
             raise ValueError(f"exchange must be one of {EXCHANGES}")
         self.params = params
@@ -717,7 +755,15 @@ class Simulation:
         elif not distributed or self.rank == 0:
             raise ValueError("obstacles may only be None on ranks other than 0 of a distributed run")
         self.obstacles = obstacles          # whole map where this rank has it (rank 0 always), else None
-        self._partitioned = self.size > 1 or bool(flags & _capi.FLAG_FORCE_HALO)
+        self.rank_grid = None
+        if rank_grid is not None:
+            px, py = int(rank_grid[0]), int(rank_grid[1])
+            if px < 1 or py < 1 or px * py != self.size:
+                raise ValueError(f"rank_grid {rank_grid} does not match {self.size} rank(s)")
+            if exchange not in ("auto", "p2p") or step_allreduce:
+                raise ValueError("the tile decomposition is stepped by the peer-to-peer loop only")
+            self.rank_grid = (px, py)
+        self._partitioned = self.size > 1 or bool(flags & _capi.FLAG_FORCE_HALO) or self.rank_grid is not None
         self._flags = flags
         self._torch_device = None
         self._stream = None
@@ -744,6 +790,8 @@ class Simulation:
             want = "rccl"
         # try the loops in order; what could not be set up on EVERY rank is skipped by all ranks together
         order = {"p2p": ["p2p", "rccl", "torch"], "rccl": ["rccl", "torch"], "torch": ["torch"]}[want]
+        if self.rank_grid is not None:
+            order = ["p2p"]
         last_err = None
         for loop in order:
             one_step = _capi.FLAG_ONE_STEP if loop == "torch" else 0
@@ -779,7 +827,9 @@ class Simulation:
                 return
             self.partition.close()
         self._partition_flags = flags
-        lay = rank_layout(self.params, self.size, self.rank, flags)
+        layout_of = ((lambda r: tile_layout(self.params, self.rank_grid[0], self.rank_grid[1], r, flags)) if self.rank_grid is not None
+                     else (lambda r: rank_layout(self.params, self.size, r, flags)))
+        lay = layout_of(self.rank)
         self.layout = lay
         self.y0, self.nyl = lay["y0"], lay["ny_local"]
         if self.exchange is not None and self.size > 1:
@@ -792,8 +842,7 @@ class Simulation:
                 box, wins = [None], None
                 if self.rank == 0:
                     free = count_free_cells(self.obstacles) if free_cells is None else free_cells
-                    wins = [(obstacle_window(self.obstacles, rank_layout(self.params, self.size, r, flags)), free)
-                            for r in range(self.size)]
+                    wins = [(obstacle_window(self.obstacles, layout_of(r)), free) for r in range(self.size)]
                 dist.scatter_object_list(box, wins, src=self.exchange._global(0), group=group)
                 self._finish_partition(box[0][0], box[0][1], flags)
                 return
@@ -804,6 +853,9 @@ class Simulation:
         self.free_cells = free_cells
         self.free_cells_inv = np.float32(1.0) / np.float32(free_cells)
         self._window = window
+        if self.rank_grid is not None:
+            self.partition = Partition(self.params, free_cells, window, device=self.device, flags=flags, tile_of=(self.rank, *self.rank_grid))
+            return
         self.partition = Partition(self.params, free_cells, window, device=self.device, flags=flags, rank_of=(self.rank, self.size))
 
     def _setup_torch_loop(self, device: int) -> None:
@@ -861,6 +913,19 @@ class Simulation:
         on_host = dist.get_backend(group) == "gloo"
         dev = torch.device("cpu") if on_host else torch.device("cuda", self.device)
         mine = torch.from_numpy(local).to(dev)
+        if self.rank_grid is not None:           # tile decomposition: rank 0 places every rank's block
+            if self.rank != 0:
+                dist.send(mine, dst=self.exchange._global(0), group=group)
+                return None
+            whole = np.empty((self.params.ny, self.params.nx) + tuple(local.shape[2:]), dtype=local.dtype)
+            for r in range(self.size):
+                lay = tile_layout(self.params, self.rank_grid[0], self.rank_grid[1], r, self._partition_flags)
+                block = mine
+                if r > 0:
+                    block = torch.empty((lay["ny_local"], lay["nx_local"]) + tuple(local.shape[2:]), dtype=mine.dtype, device=dev)
+                    dist.recv(block, src=self.exchange._global(r), group=group)
+                whole[lay["y0"]:lay["y0"] + lay["ny_local"], lay["x0"]:lay["x0"] + lay["nx_local"]] = block.cpu().numpy()
+            return whole
         if self.rank == 0:
             parts = [torch.empty((n,) + tuple(local.shape[1:]), dtype=mine.dtype, device=dev) for n in self.ny_local]
             parts[0] = mine

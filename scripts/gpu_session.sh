@@ -26,6 +26,8 @@
 #   timeline[:<bench args>]       per-dispatch start / end of the last 400 kernels of a short bench.py run (default: the 8-GPU share as a ring, 20 steps)
 #   soak                          2000-step runs x 3 of both native loops on a 1-rank ring of 8192x1024 rows, then 4 rank processes on this GPU (400 steps x 5), all parity-checked
 #   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
+#   tiles[:<case>;<case>...]      tests/tile_inprocess_worker.py per case ("nx ny px py K ghost group runs [walls]"; default: a spread of rank grids),
+#                                 each a fresh process: the ranks of a tile (2-D) decomposition on this GPU, bit for bit against the oracle
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 LBM_P2P_TIMEOUT_MS=${LBM_P2P_TIMEOUT_MS:-10000}
 TAG=$1; shift
@@ -55,6 +57,14 @@ step() {
       if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -x -q -k "$arg" > "$OUT/pytest.log" 2>&1
       else timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; fi
       local rc=$?; tail -15 "$OUT/pytest.log"; return $rc ;;
+    tiles)
+      local cases=${arg:-"512 256 1 1 4 - - 20,11;512 256 2 1 4 - - 20,11;512 256 2 2 4 - - 20,11 walls;768 384 3 2 4 - - 33;1024 512 4 2 3 - - 19,7;640 300 2 3 4 7 - 25;2048 1100 2 1 4 - - 17;2048 2048 2 2 4 - - 21"}
+      local IFS=';'
+      for cs in $cases; do
+        echo "== tiles $cs"
+        ( IFS=' '; GPU_MAX_HW_QUEUES=16 timeout -k 10 300 python tests/tile_inprocess_worker.py $cs 2>&1 | grep -v amdgpu.ids | tail -4 ) || return 1
+      done | tee "$OUT/tiles.txt"
+      ! grep -q "Error\|Traceback\|assert" "$OUT/tiles.txt" ;;
     smoke) timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee "$OUT/smoke.log" ;;
     rings) ring_lines p2p "$OUT/rings_p2p.txt" ${arg:-8192x1024 1024x128} ;;
     ringsrccl) ring_lines rccl "$OUT/rings_rccl.txt" ${arg:-8192x1024 1024x128} ;;

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lbm):
     assert declared <= exported, declared - exported
     assert declared == set(lbm.EXPORTS), declared ^ set(lbm.EXPORTS)
     lib = lbm.load_library()
-    assert lib.lbm_abi_version() == 4 == lbm._capi.ABI_VERSION
+    assert lib.lbm_abi_version() == 5 == lbm._capi.ABI_VERSION
 
 
 def test_p2p_entry_points_are_exported_by_the_core_library(lbm):
