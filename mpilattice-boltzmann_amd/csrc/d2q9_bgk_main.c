@@ -15,7 +15,9 @@
  * the reference's rule (d2q9-bgk.c:834-862), rank r lives on device LBM_DEVICES[r] (a comma list; default r), one host
  * thread per rank drives its device, and the halos travel as direct peer-to-peer stores over xGMI
  * (include/lbm_d2q9_p2p.h).  The ranks' observables are gathered in rank order — the order in which the reference's
- * ranks append to final_state.dat (:1049-1057). */
+ * ranks append to final_state.dat (:1049-1057).
+ * LBM_RANK_GRID=PXxPY (PX * PY = N) runs those N ranks as the tile (2-D) decomposition instead (lbm_create_tile): rank = ry * PX + rx owns a
+ * block of columns of a block of rows; the reference's report discusses such a split for grids wider than tall and never built it. */
 #define _POSIX_C_SOURCE 200809L
 #define _DEFAULT_SOURCE
 
@@ -127,7 +129,13 @@ int main(int argc, char* argv[])
     pthread_t* thread;
     char* handles;
     const char* list = getenv("LBM_DEVICES");
-    int r, q, t, most = 1;
+    const char* grid = getenv("LBM_RANK_GRID");
+    lbm_tile_layout* tile = NULL;
+    int r, q, t, most = 1, px = 0, py = 0;
+    if (grid && *grid) {
+      if (sscanf(grid, "%dx%d", &px, &py) != 2 || px < 1 || py < 1 || px * py != ngpus) die("LBM_RANK_GRID: expected PXxPY with PX * PY = LBM_GPUS", __LINE__, __FILE__);
+      tile = (lbm_tile_layout*)xmalloc(sizeof(lbm_tile_layout) * (size_t)ngpus);
+    }
     if (ngpus > 64) die("LBM_GPUS: at most 64 ranks (MPI_PROCS, d2q9-bgk.c:67)", __LINE__, __FILE__);
     device = (int*)xmalloc(sizeof(int) * (size_t)ngpus);
     lay = (lbm_layout*)xmalloc(sizeof(lbm_layout) * (size_t)ngpus);
@@ -156,9 +164,37 @@ int main(int argc, char* argv[])
       snprintf(budget, sizeof budget, "%d", 2 * most + 4);
       setenv("GPU_MAX_HW_QUEUES", budget, 0);
     }
+    for (r = 0; r < ngpus && tile; ++r) {
+      /* the block this rank needs: its rows and columns plus the ghost rows / columns around them, wrapping both ways */
+      int rows, cols, i, j;
+      int* window;
+      if (lbm_tile_layout_of(&params, px, py, r, flags, &tile[r])) die(lbm_last_error(), __LINE__, __FILE__);
+      rows = tile[r].ny_local + 2 * tile[r].ghost;
+      cols = tile[r].nx_local + 2 * tile[r].ghost_x;
+      window = (int*)xmalloc(sizeof(int) * (size_t)rows * (size_t)cols);
+      for (i = 0; i < rows; ++i) {
+        int g = (tile[r].y0 - tile[r].ghost + i) % params.ny;
+        if (g < 0) g += params.ny;
+        for (j = 0; j < cols; ++j) {
+          int x = (tile[r].x0 - tile[r].ghost_x + j) % params.nx;
+          if (x < 0) x += params.nx;
+          window[(size_t)i * (size_t)cols + (size_t)j] = obstacles[(size_t)g * nx + (size_t)x];
+        }
+      }
+      if (lbm_create_tile(&ctx[r], &params, free_cells, window, px, py, r, device[r], flags)) die(lbm_last_error(), __LINE__, __FILE__);
+      free(window);
+    }
     for (r = 0; r < ngpus; ++r) {
       int rows, i;
       int* window;
+      if (tile) {
+        memset(&job[r], 0, sizeof job[r]);
+        if (lbm_p2p_create(&job[r].ring, ctx[r], ngpus, r)) die(lbm_last_error(), __LINE__, __FILE__);
+        if (lbm_p2p_handle(job[r].ring, handles + (size_t)r * LBM_P2P_HANDLE_BYTES)) die(lbm_last_error(), __LINE__, __FILE__);
+        job[r].n_steps = params.max_iters;
+        job[r].tot = (double*)xmalloc(sizeof(double) * ((size_t)params.max_iters + 1));
+        continue;
+      }
       if (lbm_rank_layout(&params, ngpus, r, flags, &lay[r])) die(lbm_last_error(), __LINE__, __FILE__);
       /* the rows this rank needs: its own plus `ghost` rows below and above, wrapping (the scatter of :968-970) */
       rows = lay[r].ny_local + 2 * lay[r].ghost;
@@ -190,12 +226,20 @@ int main(int argc, char* argv[])
       for (t = 0; t < params.max_iters; ++t) av_vels[t] = (float)(job[0].tot[t] * (double)inv);   /* :367 */
     }
     for (r = 0; r < ngpus; ++r) {
-      if (lbm_get_observables(ctx[r], obs + (size_t)lay[r].y0 * nx * 4)) die(lbm_last_error(), __LINE__, __FILE__);
+      if (tile) {                                                          /* the rank's block, row by row, into its place */
+        const size_t w = (size_t)tile[r].nx_local;
+        float* block = (float*)xmalloc(sizeof(float) * 4 * w * (size_t)tile[r].ny_local);
+        int i;
+        if (lbm_get_observables(ctx[r], block)) die(lbm_last_error(), __LINE__, __FILE__);
+        for (i = 0; i < tile[r].ny_local; ++i)
+          memcpy(obs + ((size_t)(tile[r].y0 + i) * nx + (size_t)tile[r].x0) * 4, block + (size_t)i * w * 4, sizeof(float) * 4 * w);
+        free(block);
+      } else if (lbm_get_observables(ctx[r], obs + (size_t)lay[r].y0 * nx * 4)) die(lbm_last_error(), __LINE__, __FILE__);
       lbm_p2p_destroy(job[r].ring);
       free(job[r].tot);
     }
     for (r = 0; r < ngpus; ++r) lbm_destroy(ctx[r]);
-    free(device); free(lay); free(ctx); free(job); free(thread); free(handles);
+    free(device); free(lay); free(ctx); free(job); free(thread); free(handles); free(tile);
   }
   getrusage(RUSAGE_SELF, &ru);                                             /* :399-403 */
   usrtim = ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1000000.0;
@@ -209,7 +253,8 @@ int main(int argc, char* argv[])
   printf("Elapsed user CPU time:\t\t%.6lf (s)\n", usrtim);
   printf("Elapsed system CPU time:\t%.6lf (s)\n", systim);
   mlups = (double)params.nx * params.ny * params.max_iters / (toc - tic) / 1e6;
-  printf("MLUPS:\t\t\t\t%.1f (%d GPU%s)\n", mlups, ngpus > 1 ? ngpus : 1, ngpus > 1 ? "s, peer-to-peer halos" : "");
+  printf("MLUPS:\t\t\t\t%.1f (%d GPU%s%s)\n", mlups, ngpus > 1 ? ngpus : 1, ngpus > 1 ? "s, peer-to-peer halos" : "",
+         (ngpus > 1 && getenv("LBM_RANK_GRID") && *getenv("LBM_RANK_GRID")) ? ", tile decomposition" : "");
   printf("HBM roofline (108 B/cell-step @ 8.0 TB/s = 74074 MLUPS per GPU):\t%.1f %%\n",
          100.0 * mlups / (ngpus > 1 ? ngpus : 1) / (8.0e12 / 108.0 / 1e6));
 

@@ -798,7 +798,11 @@ int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)
 {
   if (!t || !text || len == 0) { lbm_internal::set_error("lbm_p2p_describe: null argument"); return 1; }
   const char* reach = "self";
-  if (t->nranks > 1) reach = (t->connected && t->peers[t->north].ipc) ? "ipc" : "in-process";
+  if (t->nranks > 1) {
+    bool ipc = t->connected && (t->peers[t->north].ipc || t->peers[t->south].ipc);
+    if (t->tiles) ipc = ipc || (t->connected && (t->peers[t->west].ipc || t->peers[t->east].ipc));   // (a 2 x 1 grid: north and south are the rank itself)
+    reach = ipc ? "ipc" : "in-process";
+  }
   if (t->ctx->ghost == 0) {
     std::snprintf(text, len, "window %s; neighbours %s; one-step mode", t->window_kind, reach);
     return 0;

@@ -9,7 +9,8 @@ Several cases per launch; rank 0 compares the gathered state with the oracle, bi
     python -m torch.distributed.run --nproc-per-node N ... tests/p2p_worker.py '<json list of cases>'
 case = {"nx", "ny", "K" (0 = library default), "schedule" ("edge" | "serial" | ""), "runs": [steps, ...], "p", "seed", "walls",
         "scatter" (only rank 0 holds the obstacle map), "exchange" ("p2p" | "rccl"), "step_allreduce",
-        "ghost", "group" (LBM_TUNE_MACRO_GHOST / _GROUP: ghost rows kept and most launches per halo exchange; default 2 K rows, two launches)}"""
+        "ghost", "group" (LBM_TUNE_MACRO_GHOST / _GROUP: ghost rows kept and most launches per halo exchange; default 2 K rows, two launches),
+        "grid" ([px, py]: the tile (2-D) decomposition over px x py = N ranks instead of row blocks; peer-to-peer loop)}"""
 import json
 import os
 import sys
@@ -48,8 +49,10 @@ def main() -> int:
         obst = lbm.synthetic_obstacles(p.nx, p.ny, c.get("p", 0.03), c.get("seed", 5), c.get("walls", False))
         mine = obst if (rank == 0 or not c.get("scatter")) else None
         sim = lbm.Simulation(p, mine, device=device, distributed=True, exchange=exchange, strict=True,
-                             step_allreduce=bool(c.get("step_allreduce")))
+                             step_allreduce=bool(c.get("step_allreduce")), rank_grid=tuple(c["grid"]) if c.get("grid") else None)
         assert sim.loop == exchange, sim.describe()
+        if c.get("grid"):
+            assert f"tiles {c['grid'][0]} x {c['grid'][1]}" in sim.describe()["p2p"], sim.describe()
         if exchange == "p2p":
             assert "ipc" in sim.describe()["p2p"], sim.describe()
             assert ("one-step" in sim.describe()["p2p"]) == (sim.partition.macro_steps == 0)

@@ -134,3 +134,45 @@ def test_p2p_connect_failure_on_one_rank_is_raised_on_every_rank(lbm, size, fail
         else:
             assert what.startswith(f"peer-to-peer connect failed on rank(s) {fail_on}: ") and "hipIpcOpenMemHandle" in what
             assert calls == "connect,disconnect,destroy"
+
+
+def _tile_worker(rank, size, init_file, grid, nx, ny, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import mpilattice_boltzmann_amd as lbm
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=size)
+    p = lbm.Params(nx, ny, 10, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(nx, ny, 0.05, 11, True)
+    # the host logic of Simulation for a tile run, with the device object left out: rank 0 alone holds the map and scatters the windows
+    # (d2q9-bgk.c:966-970 for blocks instead of rows), every rank's block is gathered into its place on rank 0
+    sim = object.__new__(lbm.Simulation)
+    sim.params, sim.device, sim._group, sim.rank_grid = p, 0, None, grid
+    sim.exchange = lbm.HaloExchange()
+    sim.rank, sim.size = sim.exchange.rank, sim.exchange.size
+    sim.obstacles = obst if rank == 0 else None
+    got = {}
+    sim._finish_partition = lambda window, free, flags: got.update(window=window, free=free)
+    sim._make_partition(0, None)
+    lay = lbm.tile_layout(p, grid[0], grid[1], rank)
+    assert sim.layout == lay and (sim.y0, sim.nyl) == (lay["y0"], lay["ny_local"])
+    assert got["free"] == lbm.count_free_cells(obst) and np.array_equal(got["window"], lbm.obstacle_window(obst, lay))
+    index = np.arange(ny * nx * 3, dtype=np.float32).reshape(ny, nx, 3)
+    mine = np.ascontiguousarray(index[lay["y0"]:lay["y0"] + lay["ny_local"], lay["x0"]:lay["x0"] + lay["nx_local"]])
+    whole = sim._gather_rows(mine)
+    assert (whole is None) == (rank != 0)
+    if rank == 0:
+        assert np.array_equal(whole, index)
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,nx,ny", [((2, 2), 512, 256), ((2, 1), 644, 128), ((3, 1), 1290, 64)])
+def test_tile_scatter_and_gather_over_gloo(lbm, grid, nx, ny):
+    """The 2-D (tile) decomposition's host side over a gloo group (world sizes 4, 2, 3): rank 0 hands every rank the window of rows AND
+    columns it needs, blocks come back into their places — uneven column blocks included."""
+    size = grid[0] * grid[1]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_tile_worker, args=(size, os.path.join(tmp, "rendezvous"), grid, nx, ny, tmp), nprocs=size, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok"))

@@ -1054,15 +1054,21 @@ P2P_CASES = {
         dict(nx=512, ny=70, K=2, schedule="edge", runs=[31], scatter=True), dict(nx=1024, ny=1024, K=0, schedule="", runs=[13, 2], walls=True),
         dict(nx=256, ny=64, K=1, schedule="serial", runs=[9]),
         # rounds 1-3's loop (an exchange before every launch), and four launches per exchange on 16 ghost rows
-        dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11], ghost="0"), dict(nx=192, ny=99, K=4, schedule="edge", runs=[37, 20], ghost="16")],
+        dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11], ghost="0"), dict(nx=192, ny=99, K=4, schedule="edge", runs=[37, 20], ghost="16"),
+        # tile (2-D) decomposition: two column blocks (each rank is its own south / north neighbour and the other's west AND east one)
+        dict(nx=512, ny=128, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True)],
     3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=4, schedule="edge", runs=[20, 21], ghost="12"), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
-        dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True)],
+        dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
+        dict(nx=772, ny=96, K=0, schedule="", runs=[13, 8], grid=[3, 1], scatter=True)],        # column blocks of 258, 258, 256
     4: [dict(nx=256, ny=131, K=3, schedule="edge", runs=[31]), dict(nx=128, ny=260, K=4, schedule="serial", runs=[17, 14]),
         dict(nx=128, ny=260, K=4, schedule="edge", runs=[17, 14], ghost="16", group="3"),
         dict(nx=2048, ny=4100, K=0, schedule="", runs=[7], scatter=True, p=0.005),
         # one-step mode: 12 / 11-row ranks, an odd row length, a 3-row last rank (d2q9-bgk.c:848-849)
         dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=37, ny=45, K=0, schedule="", runs=[19], scatter=True),
-        dict(nx=16, ny=9, K=0, schedule="", runs=[30])],
+        dict(nx=16, ny=9, K=0, schedule="", runs=[30]),
+        # tiles: 2 x 2 (corners through two hops) and four column blocks; K = 3 on 2 x 2
+        dict(nx=512, ny=256, K=0, schedule="", runs=[20, 11], grid=[2, 2], scatter=True), dict(nx=1024, ny=64, K=0, schedule="", runs=[9, 8], grid=[4, 1]),
+        dict(nx=384, ny=200, K=3, schedule="", runs=[31], grid=[2, 2], walls=True)],
 }
 
 
@@ -1172,6 +1178,55 @@ def test_p2p_partitions_in_one_process(lbm, nx, ny, size, K, schedule):
     assert r.returncode == 0 and "IN-PROCESS RING ok" in r.stdout, r.stderr[-3000:]
 
 
+TILE_CASES = [   # nx ny px py K ghost group runs [walls]
+    "512 256 1 1 4 - - 20,11",            # one rank: its own neighbour in all four directions (and on both diagonals)
+    "512 256 2 1 4 - - 20,11",            # column blocks only
+    "512 256 1 2 4 - - 20,11",            # row blocks with ghost columns that wrap onto the rank itself
+    "512 256 2 2 4 - - 20,11 walls",
+    "768 384 3 2 4 - - 33",
+    "1024 512 4 2 3 - - 19,7",            # K = 3: 15 ghost rows, 16 ghost columns, five launches per exchange
+    "640 300 2 3 4 7 - 25",               # 7 ghost rows / 8 ghost columns: one launch per exchange, the two grids as the double buffer
+    "644 300 2 3 4 12 2 25,3",            # uneven column blocks (322 = 161 pairs each ... 644 / 2), groups capped at two launches
+    "1290 200 3 2 4 0 - 18",              # 430-column blocks: storage rows of 438 floats (8-byte pushes), an exchange before every launch
+    "2048 1100 2 1 4 - - 17",             # >= 2^20 cells per rank: the tall geometry
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES)
+def test_tile_decomposition_in_one_process(lbm, case):
+    """SURVEY.md section 8(f) row 3, second half: the 2-D (tile) decomposition the reference's report discusses and never built.  The px x py
+    ranks as contexts of one process on this GPU (tests/tile_inprocess_worker.py): populations bit for bit against the oracle after
+    several runs, the per-step sums, the additive digest, observables and the velocity sum against one context holding the whole
+    grid, and a further run from a state written with lbm_set_cells."""
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", LBM_P2P_TIMEOUT_MS="10000")
+    for k in ("LBM_TUNE_MACRO_K", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_MACRO_GROUP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tile_inprocess_worker.py"), *case.split()], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "TILES ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_tile_ranks_are_refused_where_they_cannot_run(lbm):
+    """A rank of the tile decomposition is stepped by the peer-to-peer loop only: the RCCL loop, the split-phase calls and lbm_run say so
+    instead of stepping it wrongly; a transport of the wrong size is turned away at create."""
+    import ctypes as C
+    p = lbm.Params(512, 256, 10, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(512, 256, 0.03, 3, False)
+    lay = lbm.tile_layout(p, 2, 1, 0)
+    part = lbm.Partition(p, lbm.count_free_cells(obst), lbm.obstacle_window(obst, lay), tile_of=(0, 2, 1))
+    assert part.get_cells().shape == (256, 256, 9) and part.macro_steps == 4
+    with pytest.raises(lbm.LbmError, match="peer-to-peer loop"):
+        part.macro_prepare(8)
+    with pytest.raises(lbm.LbmError, match="not a self-contained domain"):
+        part.run(4)
+    with pytest.raises(lbm.LbmError, match="tile decomposition"):
+        lbm.RcclRing(part, rank=0, size=1)
+    with pytest.raises(lbm.LbmError, match="rank 0 of 2 tiles"):
+        lbm.P2PRing(part, rank=0, size=3, connect=False)
+    part.close()
+
+
 def test_p2p_refuses_ranks_with_different_layouts(lbm, monkeypatch):
     """Ranks created with different K (what per-rank decisions gave for uneven partitions) are turned away at
     connect with an error — not left to hang in the first exchange."""
@@ -1256,6 +1311,24 @@ def test_cli_drives_several_ranks_from_one_process(lbm, digests, tmp_path, gpus,
     assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
     av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+
+
+@pytest.mark.parametrize("gpus,grid,name", [(4, "2x2", "1024x1024_t200"), (2, "2x1", "256x256_t1000"), (2, "1x2", "256x256_t1000"), (8, "4x2", "1024x1024_t200")])
+def test_cli_drives_a_tile_decomposition_from_one_process(lbm, digests, tmp_path, gpus, grid, name):
+    """LBM_GPUS=N LBM_RANK_GRID=PXxPY: the same single-process host over the tile (2-D) decomposition — the shipped decks end in the
+    reference binary's final_state.dat byte for byte, whichever way the grid is cut (4 x 2: BASELINE.json config 4's eight ranks)."""
+    ppath, opath = deck_paths(name, digests)
+    env = dict(os.environ, LBM_GPUS=str(gpus), LBM_RANK_GRID=grid, LBM_DEVICES=",".join(["0"] * gpus), LBM_P2P_TIMEOUT_MS="20000")
+    r = subprocess.run([lbm.CLI_PATH, ppath, opath], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "==done==" and out[1] == digests[name]["reynolds_line"]
+    assert f"({gpus} GPUs, peer-to-peer halos, tile decomposition)" in out[5]
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
+    assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+    bad = subprocess.run([lbm.CLI_PATH, ppath, opath], cwd=tmp_path, capture_output=True, text=True, timeout=60, env=dict(env, LBM_RANK_GRID="3x5"))
+    assert bad.returncode != 0 and "LBM_RANK_GRID" in bad.stderr
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,1"])

@@ -651,6 +651,63 @@ def test_groups_of_launches_between_exchanges(lbm, monkeypatch):
     assert lbm.rank_layout(p, 8, 3)["ghost"] == 16
 
 
+def test_tile_layout_is_one_decision_for_all_ranks(lbm, monkeypatch):
+    """The tile (2-D) decomposition (the reference's report discusses it, d2q9-bgk.c:834-862 splits rows only):
+    rows by the reference's rule over py, columns in whole x-pairs over px; the blocks tile the grid exactly; K, ghost rows, ghost
+    columns (ghost rows rounded up to even) and launches per exchange are the same on every rank; a grid that would leave a rank
+    outside K-step mode is an error that names the row decomposition."""
+    import ctypes as C
+    lib = lbm._capi.load_library()
+    for nx, px in [(1024, 4), (1290, 3), (644, 2), (8192, 8), (130, 1), (10, 5)]:
+        n, d = (C.c_int * px)(), (C.c_int * px)()
+        assert lib.lbm_decompose_columns(nx, px, n, d) == 0
+        n, d = list(n), list(d)
+        assert sum(n) == nx and all(v % 2 == 0 and v > 0 for v in n) and max(n) - min(n) <= 2 and d == [sum(n[:i]) for i in range(px)]
+    assert lib.lbm_decompose_columns(129, 2, (C.c_int * 2)(), (C.c_int * 2)()) != 0           # odd nx: no whole pairs
+    assert lib.lbm_decompose_columns(8, 5, (C.c_int * 5)(), (C.c_int * 5)()) != 0             # fewer pairs than ranks
+    for nx, ny, px, py in [(8192, 8192, 4, 2), (8192, 8192, 2, 4), (1024, 1024, 4, 2), (1290, 200, 3, 2), (512, 256, 1, 1), (16384, 512, 8, 1), (768, 384, 3, 2)]:
+        p = lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
+        lays = [lbm.tile_layout(p, px, py, r) for r in range(px * py)]
+        nyl, dis = lbm.decompose(ny, py)
+        cover = np.zeros((ny, nx), dtype=np.int32)
+        for r, l in enumerate(lays):
+            assert (l["rx"], l["ry"]) == (r % px, r // px) and (l["px"], l["py"]) == (px, py)
+            assert (l["ny_local"], l["y0"]) == (nyl[l["ry"]], dis[l["ry"]])
+            cover[l["y0"]:l["y0"] + l["ny_local"], l["x0"]:l["x0"] + l["nx_local"]] += 1
+        assert np.all(cover == 1)
+        assert len({(l["macro_k"], l["ghost"], l["ghost_x"], l["group"]) for l in lays}) == 1
+        l = lays[0]
+        assert l["macro_k"] == 4 and l["ghost_x"] == (l["ghost"] + 1) // 2 * 2 and l["ghost"] <= 16
+        # as a row partition of the same cells: 8 ghost rows for ranks of >= 2 M cells, else as deep as the rows carry
+        big = max(x["nx_local"] for x in lays) * max(nyl) >= 1 << 21
+        assert l["ghost"] == (8 if big or 64 <= min(nyl) < 128 else 16 if min(nyl) >= 128 else 4)
+    monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", "7")
+    assert {(l["ghost"], l["ghost_x"], l["group"]) for l in (lbm.tile_layout(lbm.Params(640, 300, 1, 1, 0.1, 0.005, 1.85), 2, 3, r) for r in range(6))} == {(7, 8, 1)}
+    monkeypatch.delenv("LBM_TUNE_MACRO_GHOST")
+    for nx, ny, px, py in [(128, 128, 2, 2), (1024, 60, 2, 2), (1022, 512, 4, 1), (1024, 1024, 3, 2)]:      # 80-float rows; 30-row ranks; odd pairs... all fine but:
+        p = lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
+        if (nx, ny, px, py) in [(1022, 512, 4, 1), (1024, 1024, 3, 2)]:
+            assert lbm.tile_layout(p, px, py, 0)["macro_k"] == 4                              # uneven column blocks are fine
+            continue
+        with pytest.raises(lbm.LbmError, match="row decomposition"):
+            lbm.tile_layout(p, px, py, 0)
+    with pytest.raises(lbm.LbmError, match="row decomposition"):
+        lbm.tile_layout(lbm.Params(512, 256, 10, 10, 0.1, 0.005, 1.85), 2, 2, 0, lbm._capi.FLAG_ONE_STEP)
+    with pytest.raises(lbm.LbmError):
+        lbm.tile_layout(lbm.Params(512, 256, 10, 10, 0.1, 0.005, 1.85), 2, 2, 4)
+
+
+def test_tile_obstacle_window_wraps_in_both_directions(lbm):
+    p = lbm.Params(512, 256, 10, 10, 0.1, 0.005, 1.85)
+    obst = np.arange(256 * 512, dtype=np.int32).reshape(256, 512)
+    for r in range(4):
+        l = lbm.tile_layout(p, 2, 2, r)
+        w = lbm.obstacle_window(obst, l)
+        assert w.shape == (l["ny_local"] + 2 * l["ghost"], l["nx_local"] + 2 * l["ghost_x"])
+        for (i, j) in [(0, 0), (l["ghost"], l["ghost_x"]), (w.shape[0] - 1, w.shape[1] - 1), (3, w.shape[1] - 2)]:
+            assert w[i, j] == obst[(l["y0"] - l["ghost"] + i) % 256, (l["x0"] - l["ghost_x"] + j) % 512]
+
+
 def test_shipped_library_carries_no_experiment_kernels(lbm):
     """lbm_sweep_kernel and lbm_step_kernel_lds measured slower than what runs by default and are compiled only with -DLBM_EXPERIMENTS=1
     (scripts/build_variant.sh experiments; their parity tests: tests/experiments_suite.py).  The shipped code object holds neither."""
