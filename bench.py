@@ -85,6 +85,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures — N=1: the four shipped decks through lbm_run with their acceptance checks (BASELINE.json configs 2-3) "
                          "and the sustained 3 x 2000-step line; partitioned runs: the shipped 1024x1024 deck on the same ranks (config 4)")
+    ap.add_argument("--rank-grid", default="",
+                    help="PXxPY: headline over the tile (2-D) decomposition on PX x PY = N ranks instead of the reference's row blocks (peer-to-peer "
+                         "loop only; with --ring: 1x1, a rank that is its own neighbour in every direction)")
     ap.add_argument("--no-power", action="store_true", help="do not sample the card's socket power / shader clock (hwmon files) during the headline")
     ap.add_argument("--no-phases", action="store_true", help="skip the profiled extra repetition behind `phases` / the per-launch roofline timing")
     ap.add_argument("--secondary-steps", type=int, default=0, help="steps of the 1024x1024 deck (default: its own 20 000)")
@@ -612,6 +615,20 @@ def main() -> int:
     obstacles = lbm.synthetic_obstacles(nx, ny, 0.005, 42, True)
     flags = lbm._capi.FLAG_FORCE_HALO if args.ring else 0
     partitioned = world > 1 or args.ring
+    head_grid = None
+    if args.rank_grid:
+        try:
+            head_grid = tuple(int(v) for v in args.rank_grid.lower().split("x"))
+            assert len(head_grid) == 2 and head_grid[0] * head_grid[1] == world and partitioned
+        except (ValueError, AssertionError):
+            if rank == 0:
+                emit({"error": f"--rank-grid {args.rank_grid}: expected PXxPY with PX * PY = {world} ranks (and --ring on one GPU)", "n_gpus": world})
+            return 2
+
+    def default_grid(n: int):
+        """The rank grid of the `p2p_tiles` variant: as square as n allows, the longer side along x (8 -> 4 x 2)."""
+        py = max(d for d in range(1, int(n ** 0.5) + 1) if n % d == 0)
+        return (n // py, py)
 
     def fail(message: str) -> int:
         """A rank-symmetric failure: one JSON line with the reason (the self-launcher reads it), exit 1."""
@@ -665,7 +682,7 @@ def main() -> int:
 
     def single_gpu_reference(p, obst, steps_done: int, y0: int, y1: int, n_av: int):
         """(digest of rows [y0, y1), last n_av av_vels) of ONE GPU doing the whole grid for steps_done steps."""
-        key = (p.nx, p.ny, steps_done)
+        key = (p.nx, p.ny, steps_done, y0, y1)
         if key not in ref_cache:
             whole = lbm.Simulation(p, obst, device=local_rank)
             av = whole.run(steps_done)
@@ -679,9 +696,19 @@ def main() -> int:
         rows (lbm_state_checksum) and the last run's av_vels — the multi-GPU parity test, run where the GPUs are.
         Never raises (a failure on one rank must not leave the others alone in the next collective)."""
         try:
-            y0, y1 = sim.partition.y0, sim.partition.y0 + sim.partition.ny_local
-            digest, av_ref = single_gpu_reference(p, obst, steps_done, y0, y1, len(av_last))
-            same = sim.partition.checksum() == digest
+            if sim.rank_grid is not None:                 # tiles: the ranks' digests add up to the whole grid's (lbm_state_checksum is additive)
+                mine = None
+                try:
+                    mine = sim.partition.checksum()
+                except lbm.LbmError as e:
+                    sys.stderr.write(f"bench.py: rank {rank}: state digest: {e}\n")
+                every = gather(mine)                      # (every rank takes part, whatever happened to its own digest)
+                digest, av_ref = single_gpu_reference(p, obst, steps_done, 0, p.ny, len(av_last))
+                same = all(d is not None for d in every) and sum(every) % (1 << 64) == digest
+            else:
+                y0, y1 = sim.partition.y0, sim.partition.y0 + sim.partition.ny_local
+                digest, av_ref = single_gpu_reference(p, obst, steps_done, y0, y1, len(av_last))
+                same = sim.partition.checksum() == digest
             av_err = float(np.max(np.abs(av_last.astype(np.float64) - av_ref.astype(np.float64)) / av_ref.astype(np.float64))) if len(av_last) else 0.0
             return bool(same and av_err < 1e-6), same, av_err
         except (lbm.LbmError, ValueError, FloatingPointError) as e:
@@ -690,12 +717,12 @@ def main() -> int:
 
     verify_on = partitioned and not args.no_verify
 
-    def set_up(p, obst, mode: str, step_allreduce: bool, warmup: int, fl: int):
+    def set_up(p, obst, mode: str, step_allreduce: bool, warmup: int, fl: int, grid=None):
         """One loop on every rank: create, warm up, check.  Returns (sim or None, note) — rank-symmetric."""
         note, ok, sim = None, False, None
         try:
             sim = lbm.Simulation(p, obst, device=local_rank, flags=fl, distributed=world > 1, exchange=mode, strict=True,
-                                 step_allreduce=step_allreduce)
+                                 step_allreduce=step_allreduce, rank_grid=grid)
             ok = True
         except lbm.LbmError as e:                         # raised on every rank together
             sim, note = None, f"set-up: {e}"
@@ -765,6 +792,8 @@ def main() -> int:
     # ---- headline ----------------------------------------------------------------------------------------------
     if not partitioned:
         modes = ["auto"]
+    elif head_grid is not None:
+        modes = ["p2p"]
     elif args.exchange != "auto":
         modes = [args.exchange]
     else:
@@ -778,7 +807,7 @@ def main() -> int:
         if mode == "rccl" and shared_gpu:
             attempts.append({"exchange": mode, "ok": False, "error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"})
             continue
-        sim, note = set_up(params, obstacles, mode, args.step_allreduce, args.warmup, flags)
+        sim, note = set_up(params, obstacles, mode, args.step_allreduce, args.warmup, flags, head_grid)
         attempts.append({"exchange": mode, "ok": sim is not None, **({"error": note} if sim is None else {})})
         if sim is not None:
             break
@@ -892,6 +921,10 @@ def main() -> int:
             part_txt = "single GPU" if not args.ring else f"1-rank ring (self exchange), {how}: {exchange_txt}"
         else:
             part_txt = f"{world} row blocks (d2q9-bgk.c:834-862), {how}: {exchange_txt}"
+        if head_grid is not None:
+            part_txt = (f"tile (2-D) decomposition, {head_grid[0]} x {head_grid[1]} ranks: blocks of {sim_layout.get('nx_local')} x {sim_layout.get('ny_local')} cells with "
+                        f"{sim_layout.get('ghost_x')} ghost columns and {sim_layout.get('ghost')} ghost rows per side; per exchange the columns travel west / east, "
+                        f"then whole storage rows south / north; {how}: {exchange_txt}")
         out = {
             "metric": "MLUPS", "value": mlups, "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -899,6 +932,7 @@ def main() -> int:
             "config": {"workload": f"synthetic {nx}x{ny} D2Q9-BGK deck (walls + p=0.005 random obstacles, splitmix64 seed 42), "
                                    f"density 0.1 accel 0.005 omega 1.85", "nx": nx, "ny": ny, "partitioning": part_txt,
                        "loop": what["loop"], "macro_k": what["macro_k"], "ghost_rows": sim_layout.get("ghost", 0), "launches_per_exchange": sim_layout.get("group", 1),
+                       "rank_grid": list(head_grid) if head_grid is not None else None,
                        "rccl_nranks": what["rccl_nranks"], "p2p": what["p2p"],
                        "step_allreduce": what["step_allreduce"], "kernel": desc["kernel"], "control_plane": backend if world > 1 else None},
             "timing": {"reps": len(times), "settle_reps": settle_log.get("headline", 0),
@@ -1031,7 +1065,7 @@ def main() -> int:
         bank(out)
 
     # ---- partitioned runs: the RCCL loop, and north_star's per-step all-reduce, on the same deck -----------------------
-    def variant(mode: str, step_allreduce: bool, env: dict | None = None):
+    def variant(mode: str, step_allreduce: bool, env: dict | None = None, grid=None):
         def body():
             saved = {k: os.environ.get(k) for k in (env or {})}
             os.environ.update(env or {})                    # knobs read at lbm_create; the same on every rank
@@ -1047,7 +1081,7 @@ def main() -> int:
         def body_inner():
             if mode == "rccl" and shared_gpu:
                 return {"error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"}
-            vs, note = set_up(params, obstacles, mode, step_allreduce, args.warmup, flags)
+            vs, note = set_up(params, obstacles, mode, step_allreduce, args.warmup, flags, grid)
             if vs is None:
                 return {"error": note}
             vt, vav = timed(vs, args.steps, args.reps, what=f"variant {mode} {step_allreduce}")
@@ -1055,6 +1089,8 @@ def main() -> int:
             res = {"value": nx * ny * args.steps / float(np.median(vt)) / 1e6, "unit": "MLUPS", "ms_per_step": float(np.median(vt)) / args.steps * 1e3,
                    "ms_per_rep": [t * 1e3 for t in vt], **{k2: v for k2, v in vs.describe().items() if k2 in ("loop", "macro_k", "rccl_nranks", "step_allreduce")},
                    "ghost_rows": vs.layout.get("ghost"), "launches_per_exchange": vs.layout.get("group")}
+            if grid is not None:
+                res.update(rank_grid=list(grid), block=[vs.layout.get("nx_local"), vs.layout.get("ny_local")], ghost_columns=vs.layout.get("ghost_x"), p2p=vs.describe()["p2p"])
             if verify_on:
                 good, same, av_err = check_against_single_gpu(vs, params, obstacles, vav, done)
                 res["parity_ok"] = agree(good)
@@ -1076,6 +1112,13 @@ def main() -> int:
             if rank == 0:
                 out["variants"] = variants
                 bank(out)
+        # the same deck over the tile (2-D) decomposition, as square a rank grid as the ranks allow: what the
+        # smaller halo and the four neighbours are worth on real links, beside the headline's row blocks
+        if world > 1 and head_grid is None and what["loop"] == "p2p":
+            variants["p2p_tiles"] = optional_part("variant: p2p_tiles", 45.0, variant("p2p", False, None, default_grid(world)))
+            if rank == 0:
+                out["variants"] = variants
+                bank(out)
 
     # ---- BASELINE.json config 4: the shipped 1024x1024 deck on the same ranks ------------------------------------------
     def secondary_1024():
@@ -1085,11 +1128,13 @@ def main() -> int:
         n4 = args.secondary_steps if args.secondary_steps > 0 else p4.max_iters
         res = {"deck": "input_1024x1024.params + obstacles_1024x1024.dat (tests/golden/decks: the reference's own files)", "steps": n4,
                "reference_published_s": 5.90364, "reference_published_note": "d2q9-bgk_best.out:8-12, 64 MPI ranks on 4 x 16 Xeon E5-2670 cores, 20 000 steps"}
-        for mode in ("p2p", "rccl"):
+        for mode in ("p2p", "rccl", "p2p_tiles"):
             if mode == "rccl" and shared_gpu:
                 res[mode] = {"error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"}
                 continue
-            s4, note = set_up(p4, o4, mode, False, 0, flags)
+            if mode == "p2p_tiles" and world == 1:
+                continue
+            s4, note = set_up(p4, o4, "p2p" if mode == "p2p_tiles" else mode, False, 0, flags, default_grid(world) if mode == "p2p_tiles" else None)
             if s4 is None:
                 res[mode] = {"error": note}
                 continue

@@ -26,6 +26,9 @@
 #   timeline[:<bench args>]       per-dispatch start / end of the last 400 kernels of a short bench.py run (default: the 8-GPU share as a ring, 20 steps)
 #   soak                          2000-step runs x 3 of both native loops on a 1-rank ring of 8192x1024 rows, then 4 rank processes on this GPU (400 steps x 5), all parity-checked
 #   ab:<libA>,<libB>[:args]       scripts/ab_libs.py on two builds of the library (lib/variants/*.so)
+#   tilebench                     the tile decomposition's figures: a rank's block of the 8192^2 deck on 4 x 2 / 2 x 2 / 2 x 1 ranks and of the 1024^2 deck on
+#                                 4 x 2 as 1 x 1 tile rings (one per process, 300 / 3000 steps and the driver's 20) beside the row shares of the same cells
+#                                 in the same session, kernel traces of the two 8-GPU blocks, then 4 rank processes on this GPU as 2 x 2 tiles and as rows
 #   tiles[:<case>;<case>...]      tests/tile_inprocess_worker.py per case ("nx ny px py K ghost group runs [walls]"; default: a spread of rank grids),
 #                                 each a fresh process: the ranks of a tile (2-D) decomposition on this GPU, bit for bit against the oracle
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -178,6 +181,25 @@ PY
         done
       done
       LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 2 --steps 20 --warmup 5 > "$P/bench_2ranks_one_gpu_8192.json" && short "$P/bench_2ranks_one_gpu_8192.json" ;;
+    tilebench)
+      local P="$OUT/profiles"; mkdir -p "$P"
+      short() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['config']['loop'], d['config'].get('p2p'), (d.get('parity_check') or {}).get('ok'))" "$1"; }
+      # block of a 4 x 2 / 2 x 2 / 2 x 1 tiling of 8192^2 and of a 4 x 2 tiling of 1024^2, each beside the row share of the same cell count
+      for pair in 2048x4096:8192x1024 4096x4096:8192x2048 4096x8192:8192x4096 256x512:1024x128; do
+        local tl=${pair%%:*} rw=${pair#*:} st=300; [ $tl = 256x512 ] && st=3000
+        python bench.py --ring --rank-grid 1x1 --workload $tl --steps $st --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/tile_ring_${tl}.json" && short "$P/tile_ring_${tl}.json" || return 1
+        python bench.py --ring --rank-grid 1x1 --workload $tl --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-secondary > "$P/tile_ring_${tl}_s20.json" && short "$P/tile_ring_${tl}_s20.json" || return 1
+        python bench.py --ring --exchange p2p --workload $rw --steps $st --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/tile_session_row_ring_${rw}.json" && short "$P/tile_session_row_ring_${rw}.json" || return 1
+      done
+      for tl in 2048x4096 256x512; do
+        local st=300; [ $tl = 256x512 ] && st=3000
+        rm -rf "$OUT/prof_tile_$tl"
+        timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_tile_$tl" -o trace -- python3 bench.py --ring --rank-grid 1x1 --workload $tl --steps $st --warmup 30 --reps 1 --no-cpu-baseline --no-verify --no-variants --no-secondary --no-phases > /dev/null 2> "$OUT/prof_tile_$tl.err" || return 1
+        find "$OUT/prof_tile_$tl" -name '*kernel_stats.csv' -exec cp {} "$P/tile_ring_${tl}_kernel_stats.csv" \;
+        find "$OUT/prof_tile_$tl" -name '*kernel_trace.csv' -delete
+      done
+      LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 4 --rank-grid 2x2 --workload 4096x4096 --steps 20 --warmup 5 --no-secondary > "$P/bench_4ranks_one_gpu_4096_tiles_2x2.json" && short "$P/bench_4ranks_one_gpu_4096_tiles_2x2.json" || return 1
+      LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 4 --workload 4096x4096 --steps 20 --warmup 5 --no-secondary > "$P/bench_4ranks_one_gpu_4096_rows.json" && short "$P/bench_4ranks_one_gpu_4096_rows.json" ;;
     decks)
       for d in 128x128 128x256 256x256 1024x1024; do
         ( cd /tmp && "$GRAFT_REPO_ROOT/mpilattice-boltzmann_amd/bin/d2q9-bgk" "$GRAFT_REPO_ROOT/tests/golden/decks/input_$d.params" "$GRAFT_REPO_ROOT/tests/golden/decks/obstacles_$d.dat" | sed -n '2,3p;6p' | tr '\n' ' '; echo "  [$d]" )
