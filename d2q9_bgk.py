@@ -67,8 +67,17 @@ def main(argv) -> int:
     exchange = os.environ.get("LBM_EXCHANGE", "auto" if backend == "nccl" or world == 1 else "p2p")
     # the contract path forms every sum|u| term as the reference does (double precision, d2q9-bgk.c:667); LBM_FLAGS=0: the library's default
     flags = int(os.environ.get("LBM_FLAGS", lbm._capi.FLAG_EXACT_AVVELS))
+    # LBM_RANK_GRID=PXxPY (PX * PY = the ranks): the tile (2-D) decomposition instead of the reference's row blocks (peer-to-peer loop)
+    rank_grid = None
+    if os.environ.get("LBM_RANK_GRID"):
+        try:
+            rank_grid = tuple(int(v) for v in os.environ["LBM_RANK_GRID"].lower().split("x"))
+            assert len(rank_grid) == 2 and rank_grid[0] * rank_grid[1] == world
+        except (ValueError, AssertionError):
+            die("LBM_RANK_GRID: expected PXxPY with PX * PY = the number of ranks")
+        exchange = "p2p"
     try:
-        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=exchange, flags=flags)
+        sim = lbm.Simulation(params, obstacles, device=local_rank, distributed=world > 1, exchange=exchange, flags=flags, rank_grid=rank_grid)
     except lbm.LbmError as e:
         die(str(e))
     if dist is not None:
@@ -87,7 +96,8 @@ def main(argv) -> int:
         print("Elapsed user CPU time:\t\t%.6f (s)" % ru.ru_utime)
         print("Elapsed system CPU time:\t%.6f (s)" % ru.ru_stime)
         mlups = params.nx * params.ny * params.max_iters / (toc - tic) / 1e6
-        print("MLUPS:\t\t\t\t%.1f (%d GPU%s, %s loop)" % (mlups, world, "" if world == 1 else "s", sim.loop))
+        print("MLUPS:\t\t\t\t%.1f (%d GPU%s, %s loop%s)" % (mlups, world, "" if world == 1 else "s", sim.loop,
+                                                            "" if rank_grid is None else ", %d x %d tiles" % rank_grid))
         if not os.environ.get("LBM_NO_OUTPUT"):                            # :419-421
             sim.write_values(av_vels, ".", observables=obs)
     sim.close()

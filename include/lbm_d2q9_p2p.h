@@ -23,6 +23,12 @@
  *   - the end-of-run reduction is an all-gather of the per-step double sums into every rank's window and a
  *     local sum in rank order: bitwise the same vector on every rank, no collective library.
  *
+ * Ranks of the tile (2-D) decomposition (contexts from lbm_create_tile, px x py of them, nranks = px * py, rank = ry * px + rx) run the
+ * same loop with a second push in front of each exchange: my first / last r owned COLUMNS into the west / east neighbours' ghost columns
+ * (their own flags and "ready" words), awaited, and then the row push above over whole storage rows — the ghost columns that have just
+ * arrived included, which brings the corner blocks along.  Everything runs on the compute stream (every tile of a launch holds ghost
+ * columns: there is no interior part to put the exchange beside).
+ *
  * Set-up is a two-phase handshake the caller carries by any means (this repo: torch.distributed
  * all_gather of LBM_P2P_HANDLE_BYTES per rank; the C CLI: an array in its own address space):
  *     lbm_p2p_create(&t, ctx, nranks, rank);  lbm_p2p_handle(t, my_blob);
@@ -95,7 +101,7 @@ const char* lbm_p2p_phase_name(int i);
 
 /* Facts for logs and the measurement harness: how the exported window was allocated ("uncached",
  * "fine-grained" or "coarse"), how the neighbours are reached ("ipc", "in-process" or "self"), and the
- * schedule ("edge stream" = edge rows beside the interior launch, or "serial"). */
+ * schedule ("edge stream" = edge rows beside the interior launch, or "serial"); tile ranks add "tiles PX x PY; ghost columns G". */
 int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len);
 
 #ifdef __cplusplus

@@ -29,6 +29,7 @@
 #   tilebench                     the tile decomposition's figures: a rank's block of the 8192^2 deck on 4 x 2 / 2 x 2 / 2 x 1 ranks and of the 1024^2 deck on
 #                                 4 x 2 as 1 x 1 tile rings (one per process, 300 / 3000 steps and the driver's 20) beside the row shares of the same cells
 #                                 in the same session, kernel traces of the two 8-GPU blocks, then 4 rank processes on this GPU as 2 x 2 tiles and as rows
+#   tilewide                      grids much wider than tall on 8 ranks: a rank's share as a row block and as a block of an 8 x 1 tiling, 1-rank rings
 #   tiles[:<case>;<case>...]      tests/tile_inprocess_worker.py per case ("nx ny px py K ghost group runs [walls]"; default: a spread of rank grids),
 #                                 each a fresh process: the ranks of a tile (2-D) decomposition on this GPU, bit for bit against the oracle
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -200,6 +201,16 @@ PY
       done
       LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 4 --rank-grid 2x2 --workload 4096x4096 --steps 20 --warmup 5 --no-secondary > "$P/bench_4ranks_one_gpu_4096_tiles_2x2.json" && short "$P/bench_4ranks_one_gpu_4096_tiles_2x2.json" || return 1
       LBM_FORCE_DEVICE=0 timeout -k 10 500 python bench.py --gpus 4 --workload 4096x4096 --steps 20 --warmup 5 --no-secondary > "$P/bench_4ranks_one_gpu_4096_rows.json" && short "$P/bench_4ranks_one_gpu_4096_rows.json" ;;
+    tilewide)
+      # grids much wider than tall on 8 ranks ("2-D decomposition for grids wider than tall"): a rank's share as a row block
+      # (few rows: deep ghost rows cost a large share, 16 rows fall back to the one-step loop) and as a block of an 8 x 1 tiling
+      local P="$OUT/profiles"; mkdir -p "$P"
+      short() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['config']['loop'], d['config'].get('p2p'), (d.get('parity_check') or {}).get('ok'))" "$1"; }
+      for pair in 2048x512:16384x64 4096x256:32768x32 8192x128:65536x16; do
+        local tl=${pair%%:*} rw=${pair#*:}
+        python bench.py --ring --rank-grid 1x1 --workload $tl --steps 1000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/wide_tile_ring_${tl}.json" && short "$P/wide_tile_ring_${tl}.json" || return 1
+        python bench.py --ring --exchange p2p --workload $rw --steps 1000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/wide_row_ring_${rw}.json" && short "$P/wide_row_ring_${rw}.json" || return 1
+      done ;;
     decks)
       for d in 128x128 128x256 256x256 1024x1024; do
         ( cd /tmp && "$GRAFT_REPO_ROOT/mpilattice-boltzmann_amd/bin/d2q9-bgk" "$GRAFT_REPO_ROOT/tests/golden/decks/input_$d.params" "$GRAFT_REPO_ROOT/tests/golden/decks/obstacles_$d.dat" | sed -n '2,3p;6p' | tr '\n' ' '; echo "  [$d]" )

@@ -543,6 +543,28 @@ def test_several_ranks_share_the_gpu_over_gloo(lbm, digests, tmp_path, ranks, na
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
 
 
+@pytest.mark.parametrize("ranks,grid,name", [(4, "2x2", "1024x1024"), (2, "2x1", "256x256")])
+def test_rank_processes_run_a_tile_decomposition_of_the_shipped_decks(lbm, digests, tmp_path, ranks, grid, name):
+    """LBM_RANK_GRID under torch.distributed.run: the shipped decks IN FULL (20 000 / 80 000 steps) over the tile (2-D) decomposition, one
+    process per rank sharing this GPU over IPC — rank 0 parses, scatters windows of rows and columns, gathers blocks — and the files the
+    reference binary writes come out: final_state.dat byte for byte, the Reynolds line as a string."""
+    import sys
+    from conftest import ROOT
+    ppath, opath = deck_paths(name, digests)
+    env = dict(os.environ, LBM_FORCE_DEVICE="0", LBM_DIST_BACKEND="gloo", LBM_RANK_GRID=grid, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LBM_EXCHANGE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "d2q9_bgk.py"), ppath, opath]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert out[out.index("==done==") + 1] == digests[name]["reynolds_line"]
+    assert f"p2p loop, {grid[0]} x {grid[2]} tiles" in [l for l in out if l.startswith("MLUPS")][0]
+    assert sha256(tmp_path / "final_state.dat") == digests[name]["final_state_sha256"]
+    av = lbm.checker.load_av_vels(str(tmp_path / "av_vels.dat"))
+    assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
+
+
 @pytest.mark.parametrize("K", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,steps", [("synth_512x512_t100", 100), ("synth_512x512_t100", 37), ("1024x1024_t200", 200),
                                         ("128x128", 41), ("rand_64x48", 103)])
@@ -1292,8 +1314,11 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     every = out["variants"]["p2p_exchange_every_launch"]
     assert every["parity_ok"] is True and (every["ghost_rows"], every["launches_per_exchange"]) == (4, 1) and every["value"] > 0
     assert (out["config"]["ghost_rows"], out["config"]["launches_per_exchange"]) == (8, 2)
+    tiles = out["variants"]["p2p_tiles"]                            # the same deck over the tile decomposition (2 ranks: two column blocks)
+    assert tiles["parity_ok"] is True and tiles["rank_grid"] == [2, 1] and tiles["block"] == [1024, 2048] and tiles["value"] > 0
     sec = out["secondary"]["input_1024x1024"]
     assert sec["steps"] == 3000 and sec["p2p"]["parity_ok"] is True and sec["p2p"]["value"] > 0 and "ranks share a GPU" in sec["rccl"]["error"]
+    assert sec["p2p_tiles"]["parity_ok"] is True and "tiles 2 x 1" in sec["p2p_tiles"]["p2p"]
 
 
 @pytest.mark.parametrize("gpus,name", [(2, "256x256_t1000"), (3, "1024x1024_t200"), (4, "128x256_t2000"), (4, "rand_64x48"), (3, "tall_8x256")])
