@@ -223,6 +223,10 @@ void drop_graphs(lbm_ctx* c)
 int ensure_sums(lbm_ctx* c, int n)
 {
   if (n <= c->sums_cap) return 0;
+  // room for the deck's own run length from the start: growing means hipFree, which waits for the whole DEVICE — harmless for one rank per
+  // device, a dead-lock until the time-out where several ranks of one process share a device and the others already wait for this one's
+  // rows (seen in the randomised tile cases: a second run one step longer than the first)
+  n = std::max(n, std::max(c->p.max_iters, 4096));
   drop_graphs(c);   // captured kernel arguments hold the old pointer
   if (c->sums) HIP_TRY(hipFree(c->sums));
   if (c->sums_host) HIP_TRY(hipHostFree(c->sums_host));

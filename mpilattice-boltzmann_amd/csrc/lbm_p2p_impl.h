@@ -291,7 +291,18 @@ int p2p_check_error(lbm_p2p* t)
   const int e = *t->err;
   const char* who = e >= 100 ? "a neighbour's grids are out of step with this rank's (different number of steps run ?)"
                              : "a peer's data did not arrive in time (peer failed or never started the run ?)";
-  lbm_internal::set_error("lbm_p2p_run: rank " + std::to_string(t->rank) + ": " + who + " [code " + std::to_string(e) + "]");
+  // what this rank's window held when it gave up: the epochs of the rows / columns that have arrived and of the neighbours' "ready" words
+  std::string words;
+  P2PWindowHeader h{};
+  if (hipMemcpy(&h, t->window, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+    words = "; epoch " + std::to_string(t->epoch) + ", rows from south / north " + std::to_string(h.halo_flag[0]) + " / " + std::to_string(h.halo_flag[1]) +
+            ", ready south / north " + std::to_string(h.halo_ack[0]) + " / " + std::to_string(h.halo_ack[1]);
+    if (t->tiles)
+      words += ", columns from west / east " + std::to_string(h.halo_flag_x[0]) + " / " + std::to_string(h.halo_flag_x[1]) + ", ready west / east " +
+               std::to_string(h.halo_ack[2]) + " / " + std::to_string(h.halo_ack[3]);
+  }
+  (void)hipGetLastError();
+  lbm_internal::set_error("lbm_p2p_run: rank " + std::to_string(t->rank) + ": " + who + " [code " + std::to_string(e) + words + "]");
   return 1;
 }
 
@@ -412,7 +423,9 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   // exported window: flags + reduce slots.  Uncached device memory, so that a flag raised by a peer is seen
   // by a kernel that is already running here; fine-grained, then ordinary memory as fall-backs.
   t->reduce_cap = static_cast<size_t>(std::max(ctx->p.max_iters, 4096));
-  t->halo_bytes = round_up(sizeof(float) * 2 * 2 * 3 * static_cast<size_t>(ctx->nxp), 256);
+  // (the one-step mode's halo slots; the reduce slots behind them must lie at the same offset in EVERY rank's window: tile ranks — always
+  // K-step mode, storage rows of different widths where the column blocks are uneven — keep none)
+  t->halo_bytes = t->tiles ? 0 : round_up(sizeof(float) * 2 * 2 * 3 * static_cast<size_t>(ctx->nxp), 256);
   t->window_bytes = kP2PHeaderBytes + t->halo_bytes + sizeof(double) * 2 * nranks * t->reduce_cap;
   // The protocol needs a window whose flags a running kernel sees change and whose one-step halo slots need no
   // cache maintenance on the reader's side: uncached, or fine-grained as the fall-back.  Ordinary (coarse-grained)

@@ -640,9 +640,11 @@ class P2PRing:
             t.start()
         for t in threads:
             t.join()
-        for o in out:
-            if isinstance(o, Exception):
-                raise o
+        errors = [(i, o) for i, o in enumerate(out) if isinstance(o, Exception)]
+        if errors:
+            # every rank's own words: the ranks that only waited for a failed one say "did not arrive in time", the failed one says why
+            first = next((o for _, o in errors if "did not arrive" not in str(o)), errors[0][1])
+            raise type(first)("; ".join(f"rank {i}: {o}" for i, o in errors)) from first
         return out
 
     def describe(self) -> str:

@@ -217,7 +217,8 @@ PY
       done | tee "$OUT/cli_decks.txt" ;;
     fuzz)
       local n=${arg%%:*} seed=4; [ "$n" != "$arg" ] && seed=${arg#*:}
-      timeout -k 10 1000 python scripts/fuzz_kernels.py --cases ${n:-150} --seed $seed 2>&1 | grep -v amdgpu.ids | tail -12 | tee "$OUT/fuzz_$seed.log" ;;
+      timeout -k 10 1000 python scripts/fuzz_kernels.py --cases ${n:-150} --seed $seed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_$seed.log"
+      local rc=$?; tail -14 "$OUT/fuzz_$seed.log"; return $rc ;;
     timeline)
       # kernel-by-kernel timeline of short runs: rocprofv3 --kernel-trace of <bench args>, the dispatch table kept (timeline.csv: name, start, end in ns)
       rm -rf "$OUT/timeline"

@@ -1211,6 +1211,11 @@ TILE_CASES = [   # nx ny px py K ghost group runs [walls]
     "644 300 2 3 4 12 2 25,3",            # uneven column blocks (322 = 161 pairs each ... 644 / 2), groups capped at two launches
     "1290 200 3 2 4 0 - 18",              # 430-column blocks: storage rows of 438 floats (8-byte pushes), an exchange before every launch
     "2048 1100 2 1 4 - - 17",             # >= 2^20 cells per rank: the tall geometry
+    # uneven column blocks (162, 162, 160 and 344, 342, 342 columns: storage rows of different widths on the ranks of one row of the rank
+    # grid) — the per-step sums of every rank must land in the same slot of every window; and a second run longer than the first
+    "484 78 3 1 1 4 2 9,9",
+    "1028 200 3 1 4 - - 10,11",
+    "590 267 2 3 1 16 - 18,19",           # K = 1: eight one-step launches per exchange
 ]
 
 
