@@ -1131,8 +1131,11 @@ MULTI_GPU_CASES = {
         dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6]), dict(nx=64, ny=48, K=0, schedule="", runs=[25, 6], exchange="rccl"),
         # four launches per exchange on 16 ghost rows (ranks of 200 rows), over both loops and both schedules; three on 12
         dict(nx=256, ny=400, K=0, schedule="", runs=[37, 20]), dict(nx=256, ny=400, K=0, schedule="edge", runs=[37, 20], exchange="rccl"),
-        dict(nx=1024, ny=300, K=4, schedule="edge", runs=[21, 20], ghost="12", scatter=True)],
+        dict(nx=1024, ny=300, K=4, schedule="edge", runs=[21, 20], ghost="12", scatter=True),
+        # tile (2-D) decomposition over a real link: two column blocks (columns west / east across the link, rows onto the rank itself)
+        dict(nx=2048, ny=1100, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True, p=0.005), dict(nx=484, ny=78, K=1, schedule="", runs=[9, 10], grid=[2, 1], ghost="4", group="2")],
     3: [dict(nx=256, ny=200, K=3, schedule="edge", runs=[20, 11]), dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
+        dict(nx=772, ny=96, K=0, schedule="", runs=[13, 8], grid=[3, 1], scatter=True),
         dict(nx=256, ny=200, K=3, schedule="", runs=[20, 11], exchange="rccl", scatter=True),
         dict(nx=1000, ny=400, K=0, schedule="", runs=[16], walls=True, exchange="rccl", step_allreduce=True),
         dict(nx=37, ny=45, K=0, schedule="", runs=[19], scatter=True), dict(nx=37, ny=45, K=0, schedule="", runs=[19], exchange="rccl", step_allreduce=True)],
@@ -1216,6 +1219,8 @@ TILE_CASES = [   # nx ny px py K ghost group runs [walls]
     "484 78 3 1 1 4 2 9,9",
     "1028 200 3 1 4 - - 10,11",
     "590 267 2 3 1 16 - 18,19",           # K = 1: eight one-step launches per exchange
+    "512 256 2 2 4 - - 20,11 walls flags=64",     # the other two forms of the sum|u| terms in the tile launch form (LBM_FLAG_FAST_AVVELS / _EXACT_AVVELS)
+    "768 384 3 2 4 - - 33 flags=128",
 ]
 
 
