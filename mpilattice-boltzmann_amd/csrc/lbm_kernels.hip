@@ -1189,7 +1189,7 @@ int lbm_get_observables(lbm_ctx* c, float* obs)
   // row blocks of at most 16 M cells through a 256 MB device buffer: no second copy of the state
   // (whole rows per block, so that a block of a tile rank's column window starts on a row)
   const size_t total = owned_cells(c);
-  const size_t chunk = std::min<size_t>(total, std::max<size_t>(1, (size_t(16) << 20) / c->nxl) * c->nxl);
+  const size_t chunk = std::min<size_t>(total, std::max<size_t>(1, static_cast<size_t>(tune_env("LBM_TUNE_OBS_CHUNK_CELLS", 16 << 20)) / c->nxl) * c->nxl);
   float* tmp = nullptr;
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * 4 * chunk));
   hipError_t e = hipSuccess;

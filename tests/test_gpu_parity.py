@@ -1239,6 +1239,47 @@ def test_tile_decomposition_in_one_process(lbm, case):
     assert r.returncode == 0 and "TILES ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
+def test_tile_context_moves_and_digests_its_block_through_a_column_window(lbm, oracle, monkeypatch):
+    """lbm_get_cells / _set_cells / _get_observables / _state_checksum / _av_velocity_sum of a tile rank see its ny_local x nx_local block
+    inside storage rows that also hold ghost columns: random state in, the same state out; observables in row chunks (as blocks of more
+    than 16 M cells are fetched) equal to one fetch and to a whole-grid context's; digests of row ranges add up."""
+    p = lbm.Params(512, 256, 10, 4, 0.1, 0.01, 1.7)
+    obst = lbm.synthetic_obstacles(512, 256, 0.03, 3, False)
+    free = lbm.count_free_cells(obst)
+    lay = lbm.tile_layout(p, 2, 2, 3)
+    part = lbm.Partition(p, free, lbm.obstacle_window(obst, lay), tile_of=(3, 2, 2))
+    rng = np.random.default_rng(5)
+    state = (rng.random((256, 512, 9), dtype=np.float32) * 0.02 + 0.004).astype(np.float32)
+    ys, xs = slice(lay["y0"], lay["y0"] + lay["ny_local"]), slice(lay["x0"], lay["x0"] + lay["nx_local"])
+    part.set_cells(state[ys, xs])
+    assert np.array_equal(part.get_cells().view(np.uint32), state[ys, xs].view(np.uint32))
+    whole = lbm.Partition(p, free, obst)
+    whole.set_cells(state)
+    obs = part.get_observables()
+    assert np.array_equal(obs.view(np.uint32), whole.get_observables()[ys, xs].view(np.uint32))
+    monkeypatch.setenv("LBM_TUNE_OBS_CHUNK_CELLS", str(37 * lay["nx_local"] + 5))      # 37 rows per fetch
+    assert np.array_equal(part.get_observables().view(np.uint32), obs.view(np.uint32))
+    monkeypatch.delenv("LBM_TUNE_OBS_CHUNK_CELLS")
+    y0, y1 = lay["y0"], lay["y0"] + lay["ny_local"]
+    mid = y0 + 51
+    assert (part.checksum(y0, mid) + part.checksum(mid, y1)) % (1 << 64) == part.checksum() and part.checksum(mid, mid) == 0
+    # the four blocks of the grid, each set from the same state, add up to the whole grid's digest
+    total = part.checksum()
+    for r in range(3):
+        l = lbm.tile_layout(p, 2, 2, r)
+        q = lbm.Partition(p, free, lbm.obstacle_window(obst, l), tile_of=(r, 2, 2))
+        q.set_cells(state[l["y0"]:l["y0"] + l["ny_local"], l["x0"]:l["x0"] + l["nx_local"]])
+        total = (total + q.checksum()) % (1 << 64)
+        q.close()
+    assert total == whole.checksum()
+    want = sum(float(np.sqrt(np.float64(o[0] * o[0] + o[1] * o[1]))) for o in obs[obst[ys, xs] == 0])
+    assert abs(part.av_velocity_sum() - want) <= 1e-9 * want
+    with pytest.raises(lbm.LbmError, match="rows outside"):
+        part.checksum(0, 10)
+    part.close()
+    whole.close()
+
+
 def test_tile_ranks_are_refused_where_they_cannot_run(lbm):
     """A rank of the tile decomposition is stepped by the peer-to-peer loop only: the RCCL loop, the split-phase calls and lbm_run say so
     instead of stepping it wrongly; a transport of the wrong size is turned away at create."""
