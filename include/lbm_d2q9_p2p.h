@@ -26,8 +26,9 @@
  * Ranks of the tile (2-D) decomposition (contexts from lbm_create_tile, px x py of them, nranks = px * py, rank = ry * px + rx) run the
  * same loop with a second push in front of each exchange: my first / last r owned COLUMNS into the west / east neighbours' ghost columns
  * (their own flags and "ready" words), awaited, and then the row push above over whole storage rows — the ghost columns that have just
- * arrived included, which brings the corner blocks along.  Everything runs on the compute stream (every tile of a launch holds ghost
- * columns: there is no interior part to put the exchange beside).
+ * arrived included, which brings the corner blocks along.  The part of a group's first launch that runs beside the exchange is the
+ * rectangle of tiles inside the rim of tile rows and tile columns that read exchanged cells (ranks of >= 2^25 cells; smaller ones run
+ * everything on the compute stream).
  *
  * Set-up is a two-phase handshake the caller carries by any means (this repo: torch.distributed
  * all_gather of LBM_P2P_HANDLE_BYTES per rank; the C CLI: an array in its own address space):

@@ -135,6 +135,10 @@ struct MultiArgs {
   // the ghost columns the later launches of the group read; both even), and counts the owned columns [cx0, cx1).
   int keep_x0, keep_x1, cx0, cx1;
   unsigned long long* ready_x[2]; // ... and its ready words for the west and the east neighbour (this rank's: wait_ready[2], [3])
+  // ... and the tiles of a launch as up to four RECTANGLES of the tile grid instead of two tile ranges (nrect > 0): the part of a group's first
+  // launch that reads no exchanged row or column is one rectangle (tile rows x tile columns inside the rim), the rim the four around it.
+  int nrect;
+  struct Rect { int ty0, tx0, ntx, count; } rect[4];       // tile rows from ty0, tile columns [tx0, tx0 + ntx); count = rows x ntx blocks
 };
 
 // A pair (x, x+1), x even, of population k into row `row` (a dword index) of an LDS frame of row stride W: interleaved
@@ -225,7 +229,22 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     const int nb = gridDim.x - 1, per = nb >> 3;
     b = (b & 7) * per + (b >> 3);
   }
-  const int tile = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
+  int tile_of_block = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
+  if constexpr (PART == kPartTile) {
+    if (a.nrect > 0) {                               // block -> rectangle -> tile (block-uniform scalar work; constant indices: the arguments stay in SGPRs)
+      int q = b, ty0 = a.rect[0].ty0, tx0 = a.rect[0].tx0, ntx = a.rect[0].ntx;
+      if (a.nrect > 1 && q >= a.rect[0].count) {
+        q -= a.rect[0].count; ty0 = a.rect[1].ty0; tx0 = a.rect[1].tx0; ntx = a.rect[1].ntx;
+        if (a.nrect > 2 && q >= a.rect[1].count) {
+          q -= a.rect[1].count; ty0 = a.rect[2].ty0; tx0 = a.rect[2].tx0; ntx = a.rect[2].ntx;
+          if (a.nrect > 3 && q >= a.rect[2].count) { q -= a.rect[2].count; ty0 = a.rect[3].ty0; tx0 = a.rect[3].tx0; ntx = a.rect[3].ntx; }
+        }
+      }
+      const int rr = q / ntx;
+      tile_of_block = (ty0 + rr) * a.tiles_x + tx0 + (q - rr * ntx);
+    }
+  }
+  const int tile = tile_of_block;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int x0 = tx * TX;
   const int sy0 = a.row_first + ty * TY;          // storage row of the tile's first row

@@ -350,7 +350,8 @@ int multi_tiles_for(const lbm_ctx* c, int k, int ext = 0) { return c->multi_tile
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps of the owned rows and `ext`
 // ghost rows on each side (tile row 0 starts at storage row ghost - ext).
-void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int n0, int t1, int n1, bool fold, hipStream_t s)
+void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int n0, int t1, int n1, bool fold, hipStream_t s,
+                  const MultiArgs::Rect* rects = nullptr, int nrect = 0)    // rects: the launch's tiles as rectangles of the tile grid (tile ranks) instead of t0 .. n1
 {
   MultiArgs a{};
   a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
@@ -375,7 +376,12 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.ready_epoch = c->ready_epoch;
   a.wait_ready = c->ready_epoch ? c->ready_wait : nullptr; a.timeout_ticks = c->ready_timeout_ticks; a.err = c->ready_err;
   c->ready_epoch = 0;
-  const int blocks = n0 + n1;
+  int blocks = n0 + n1;
+  if (nrect > 0) {
+    blocks = 0;
+    a.nrect = nrect; a.tile_count = 0; a.tile_count2 = 0;
+    for (int i = 0; i < nrect; ++i) { a.rect[i] = rects[i]; blocks += rects[i].count; }
+  }
   // measured on 8192x8192, K=2: 515 us/step with the XCD-contiguous tile order, 549 without
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
@@ -1438,7 +1444,9 @@ int lbm_macro_next_launches(const lbm_ctx* c) { return (c && c->ghost > 0 && c->
 // first `bottom_edge_rows` and the last `top_edge_rows` tile rows read exchanged rows (edge launch, after the exchange); the
 // `interior_rows` between them do not: the rows they need — their own, k below and k above — are owned rows.  (The last tile row
 // may hold fewer rows than a launch makes steps: the ring of the row below then reaches the ghost rows, and the top edge is two rows.)
-struct MacroRows { int bottom_edge_rows, interior_rows, top_edge_rows; };
+// (Tile ranks: the first `left_cols` and the last `right_cols` tile COLUMNS read exchanged columns as well — a tile's first sub-step reads
+// 2 (k - 1) + 1 columns beyond its own on each side; the interior is then the rectangle inside all four.)
+struct MacroRows { int bottom_edge_rows, interior_rows, top_edge_rows, left_cols, right_cols; };
 static MacroRows macro_rows(const lbm_ctx* c, int k, int ext = 0)
 {
   const int ty = multi_ty(k, c->multi_geom);
@@ -1448,13 +1456,45 @@ static MacroRows macro_rows(const lbm_ctx* c, int k, int ext = 0)
   int b = 0, t = 0;
   while (b < nty && first + b * ty - k < lo) ++b;
   while (t < nty - b && std::min(first + (nty - t) * ty, first + rows) - 1 + k >= hi) ++t;
-  return {b, nty - b - t, t};
+  int l = 0, r = 0;
+  if (c->ghost_x > 0) {
+    const int tx = c->multi_tx, ntx = c->multi_tiles_x, reach = 2 * (k - 1) + 1;
+    const int xlo = c->ghost_x, xhi = c->ghost_x + c->nxl;         // the owned columns [xlo, xhi)
+    while (l < ntx && l * tx - reach < xlo) ++l;
+    while (r < ntx - l && (ntx - r) * tx - 1 + reach >= xhi) ++r;
+    if (ntx - l - r <= 0) return {nty, 0, 0, 0, 0};               // no tile column inside the rim: everything waits for the exchange
+  }
+  return {b, nty - b - t, t, l, r};
+}
+
+// The tiles of a tile rank's launch of k steps + ext as rectangles: the interior (at most one), or the rim around it (at most four).
+static int macro_rects(const lbm_ctx* c, int k, int ext, bool interior, MultiArgs::Rect* out)
+{
+  const MacroRows m = macro_rows(c, k, ext);
+  const int ntx = c->multi_tiles_x, mid = m.interior_rows;
+  int n = 0;
+  auto add = [&](int ty0, int nrows, int tx0, int cols) { if (nrows > 0 && cols > 0) out[n++] = MultiArgs::Rect{ty0, tx0, cols, nrows * cols}; };
+  if (interior) {
+    add(m.bottom_edge_rows, mid, m.left_cols, ntx - m.left_cols - m.right_cols);
+  } else {
+    add(0, m.bottom_edge_rows, 0, ntx);
+    add(m.bottom_edge_rows + mid, m.top_edge_rows, 0, ntx);
+    add(m.bottom_edge_rows, mid, 0, m.left_cols);
+    add(m.bottom_edge_rows, mid, ntx - m.right_cols, m.right_cols);
+  }
+  return n;
 }
 
 // The launches of a group, called by both native loops and by the split-phase entry points below.
 static void launch_group_interior(lbm_ctx* c, const GroupPlan& g, bool more_after_group, hipStream_t s)
 {
   const int k = g.k[0], ext = g.ext(0);
+  if (c->ghost_x > 0) {                                            // tile rank: the rectangle inside the rim
+    MultiArgs::Rect rects[4];
+    const int n = macro_rects(c, k, ext, true, rects);
+    launch_multi(c, k, ext, /*accel_last=*/g.n > 1 || more_after_group, 0, 0, 0, 0, /*fold=*/c->n_prev > 0, s, rects, n);
+    return;
+  }
   const MacroRows r = macro_rows(c, k, ext);
   launch_multi(c, k, ext, /*accel_last=*/g.n > 1 || more_after_group, r.bottom_edge_rows * c->multi_tiles_x, r.interior_rows * c->multi_tiles_x, 0, 0,
                /*fold=*/c->n_prev > 0, s);
@@ -1462,6 +1502,12 @@ static void launch_group_interior(lbm_ctx* c, const GroupPlan& g, bool more_afte
 static void launch_group_edge(lbm_ctx* c, const GroupPlan& g, bool more_after_group, hipStream_t s)
 {
   const int k = g.k[0], ext = g.ext(0);
+  if (c->ghost_x > 0) {                                            // tile rank: the rim, four rectangles at most
+    MultiArgs::Rect rects[4];
+    const int n = macro_rects(c, k, ext, false, rects);
+    launch_multi(c, k, ext, /*accel_last=*/g.n > 1 || more_after_group, 0, 0, 0, 0, /*fold=*/c->n_prev > 0, s, rects, n);
+    return;
+  }
   const MacroRows r = macro_rows(c, k, ext);
   launch_multi(c, k, ext, /*accel_last=*/g.n > 1 || more_after_group, 0, r.bottom_edge_rows * c->multi_tiles_x,
                (r.bottom_edge_rows + r.interior_rows) * c->multi_tiles_x, r.top_edge_rows * c->multi_tiles_x, /*fold=*/c->n_prev > 0, s);

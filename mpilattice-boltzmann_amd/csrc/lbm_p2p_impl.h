@@ -398,8 +398,12 @@ int lbm_p2p_create(lbm_p2p** out, lbm_ctx* ctx, int nranks, int rank)
   // default by size, as the RCCL loop: an own stream for the edge rows pays once the interior launch is long
   // enough to cover two cross-queue waits
   t->edge_stream = ctx->ncells >= (size_t(1) << 21);
-  if (t->tiles) t->edge_stream = false;      // every tile of a launch holds ghost columns: nothing to run beside the exchange
-  else if (const char* sched = std::getenv("LBM_P2P_SCHEDULE")) {
+  // Tile ranks: the interior is the rectangle of tiles inside the rim of tile rows AND tile columns that read exchanged cells (macro_rects).
+  // That rim is a round of blocks by itself (a 2048 x 4096 block: 422 of its 5874 tiles, 46 us) where a row block's is two tile rows, and the
+  // exchange it hides is short (31 us per 8 steps): 1-rank rings, us/step serial / edge stream: 2048 x 4096 45.5 / 46.5, 4096 x 4096 82.0 / 82.4,
+  // 4096 x 8192 158.0 / 155.5 (profiles/r04/tile_ring_*_{serial,edge_stream}.json) — from 2^25 cells up
+  if (t->tiles) t->edge_stream = ctx->ncells >= (size_t(1) << 25);
+  if (const char* sched = std::getenv("LBM_P2P_SCHEDULE")) {
     if (std::string(sched) == "serial") t->edge_stream = false;
     if (std::string(sched) == "edge") t->edge_stream = true;
   }
@@ -734,7 +738,7 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       if (t->edge_stream) {
         // the rows to push are the last launch's: its edge rows when the group was one launch and those tile rows hold all
         // next.total rows of either side (then the push need not wait for the interior launch); else the compute stream's
-        const bool edge_rows_suffice = g.n == 1 && (c->ghost - g.ext(0)) + rows.bottom_edge_rows * multi_ty(g.k[0], c->multi_geom) >= c->ghost + next.total &&
+        const bool edge_rows_suffice = g.n == 1 && !t->tiles && (c->ghost - g.ext(0)) + rows.bottom_edge_rows * multi_ty(g.k[0], c->multi_geom) >= c->ghost + next.total &&
                                        (c->ghost - g.ext(0)) + (rows.bottom_edge_rows + rows.interior_rows) * multi_ty(g.k[0], c->multi_geom) <= c->ghost + c->nyl - next.total;
         if (!edge_rows_suffice) { P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0)); es_has_waited = true; }
       }

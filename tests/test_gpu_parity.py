@@ -1078,7 +1078,8 @@ P2P_CASES = {
         # rounds 1-3's loop (an exchange before every launch), and four launches per exchange on 16 ghost rows
         dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11], ghost="0"), dict(nx=192, ny=99, K=4, schedule="edge", runs=[37, 20], ghost="16"),
         # tile (2-D) decomposition: two column blocks (each rank is its own south / north neighbour and the other's west AND east one)
-        dict(nx=512, ny=128, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True)],
+        dict(nx=512, ny=128, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True),
+        dict(nx=1024, ny=256, K=0, schedule="edge", runs=[20, 11], grid=[2, 1]), dict(nx=1024, ny=256, K=4, schedule="edge", runs=[9, 8], grid=[1, 2], ghost="0")],
     3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=4, schedule="edge", runs=[20, 21], ghost="12"), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
         dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
         dict(nx=772, ny=96, K=0, schedule="", runs=[13, 8], grid=[3, 1], scatter=True)],        # column blocks of 258, 258, 256
@@ -1090,7 +1091,8 @@ P2P_CASES = {
         dict(nx=16, ny=9, K=0, schedule="", runs=[30]),
         # tiles: 2 x 2 (corners through two hops) and four column blocks; K = 3 on 2 x 2
         dict(nx=512, ny=256, K=0, schedule="", runs=[20, 11], grid=[2, 2], scatter=True), dict(nx=1024, ny=64, K=0, schedule="", runs=[9, 8], grid=[4, 1]),
-        dict(nx=384, ny=200, K=3, schedule="", runs=[31], grid=[2, 2], walls=True)],
+        dict(nx=384, ny=200, K=3, schedule="", runs=[31], grid=[2, 2], walls=True),
+        dict(nx=1024, ny=512, K=0, schedule="edge", runs=[20, 11], grid=[2, 2], scatter=True)],
 }
 
 
@@ -1219,6 +1221,12 @@ TILE_CASES = [   # nx ny px py K ghost group runs [walls]
     "484 78 3 1 1 4 2 9,9",
     "1028 200 3 1 4 - - 10,11",
     "590 267 2 3 1 16 - 18,19",           # K = 1: eight one-step launches per exchange
+    # the edge-stream schedule of a tile rank: the rectangle of tiles inside the rim beside the exchange, the rim behind it
+    "512 256 1 1 4 - - 20,11 sched=edge",
+    "512 256 1 1 4 0 - 20,11 walls sched=edge",          # one launch per exchange
+    "580 300 1 1 3 - - 31 sched=edge",
+    "2048 1100 1 1 4 - - 17,8 sched=edge",
+    "448 256 4 1 4 - - 13,9",             # blocks narrower than two tiles: 112 owned columns in storage rows of 144
     "512 256 2 2 4 - - 20,11 walls flags=64",     # the other two forms of the sum|u| terms in the tile launch form (LBM_FLAG_FAST_AVVELS / _EXACT_AVVELS)
     "768 384 3 2 4 - - 33 flags=128",
 ]

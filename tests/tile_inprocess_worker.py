@@ -1,7 +1,8 @@
 """The ranks of a px x py TILE (2-D) decomposition as contexts of ONE process, one host thread per rank (test helper, run as a
 fresh process by tests/test_gpu_parity.py with GPU_MAX_HW_QUEUES raised, as tests/p2p_inprocess_worker.py).  Every rank keeps ghost
 rows and ghost columns; per exchange the columns travel west / east first, then whole storage rows south / north.
-argv: nx ny px py K ghost group runs(comma separated) [walls] [flags=<lbm_create flags>]"""
+argv: nx ny px py K ghost group runs(comma separated) [walls] [flags=<lbm_create flags>] [sched=edge|serial]
+(ranks of one process on one device run the serial schedule whatever is asked for; a 1 x 1 grid takes the edge-stream schedule when asked)"""
 import os
 import sys
 
@@ -18,6 +19,10 @@ def main() -> int:
     runs = [int(v) for v in sys.argv[8].split(",")]
     walls = "walls" in sys.argv[9:]
     flags = next((int(a.split("=")[1]) for a in sys.argv[9:] if a.startswith("flags=")), 0)
+    sched = next((a.split("=")[1] for a in sys.argv[9:] if a.startswith("sched=")), "")
+    os.environ.pop("LBM_P2P_SCHEDULE", None)
+    if sched:
+        os.environ["LBM_P2P_SCHEDULE"] = sched
     if K:
         os.environ["LBM_TUNE_MACRO_K"] = str(K)
     if ghost != "-":
@@ -41,7 +46,7 @@ def main() -> int:
     assert all(q.tile_info() == lays[r] for r, q in enumerate(parts)), (parts[0].tile_info(), lays[0])
     rings = lbm.P2PRing.local_ring(parts)
     d = rings[0].describe()
-    assert f"tiles {px} x {py}" in d and "serial" in d, d
+    assert f"tiles {px} x {py}" in d and ("edge stream" if (sched == "edge" and size == 1) else "serial") in d, d
     out = [lbm.P2PRing.run_all(rings, n) for n in runs]
     for o in out:
         for r in range(1, size):                                # the reduction is bitwise the same on every rank
