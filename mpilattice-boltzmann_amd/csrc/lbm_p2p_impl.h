@@ -203,7 +203,7 @@ int p2p_push_cols(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s)
   };
   const int per = all_mult(4) ? 4 : all_mult(2) ? 2 : 1;
   const int work = 18 * c->nyl * (k / per);
-  const dim3 grid(std::max(1, std::min(kP2PPushBlocks, (work + 1023) / 1024)));
+  const dim3 grid(std::max(1, std::min(std::max(1, tune_env("LBM_P2P_PUSH_BLOCKS_SERIAL", kP2PPushBlocks)), (work + 1023) / 1024)));
   if (per == 4) hipLaunchKernelGGL(lbm_p2p_push_cols_kernel<f4>, grid, dim3(256), 0, s, a);
   else if (per == 2) hipLaunchKernelGGL(lbm_p2p_push_cols_kernel<f2>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(lbm_p2p_push_cols_kernel<float>, grid, dim3(256), 0, s, a);
@@ -248,8 +248,11 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
   // (`exposed`: the push before the first macro-step of a run in the serial schedule, which nothing overlaps)
   // (pushes of more than four rows, round 4: twice the blocks — 8 rows beside the interior launch of 8192 x 1024 rows, us/step at 20 / 200
   // steps per run for 16 / 32 / 64 / 128 blocks: 51.9 / 49.4, 46.9 / 43.5, 47.0 / 43.1, 48.6 / 44.0; profiles/r04/ring_push_blocks.txt)
-  const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge * (k > 4 ? 2 : 1) : kP2PPushBlocks;
-  const dim3 grid(std::max(1, std::min(max_blocks, (work + 1023) / 1024)));
+  const int max_blocks = (t->edge_stream && !exposed) ? t->push_blocks_edge * (k > 4 ? 2 : 1) : std::max(1, tune_env("LBM_P2P_PUSH_BLOCKS_SERIAL", kP2PPushBlocks));
+  // (exposed push of a 1024 x 128-row rank, 16 rows: us/step at 200 steps for 32 / 64 / 72 blocks of 1024 vectors 3.59 / 3.50 - 3.55 / 3.51, 144 blocks of
+  // 512 vectors 3.61, 288 of 256 3.90 — the block count is not the lever; profiles/r04/ring_push_blocks_serial.txt)
+  const int per_block = std::max(256, tune_env("LBM_P2P_PUSH_WORK_PER_BLOCK", 1024));
+  const dim3 grid(std::max(1, std::min(max_blocks, (work + per_block - 1) / per_block)));
   if (wide) hipLaunchKernelGGL(lbm_p2p_push_kernel<f4>, grid, dim3(256), 0, s, a, nx);
   else hipLaunchKernelGGL(lbm_p2p_push_kernel<f2>, grid, dim3(256), 0, s, a, nx);
   HIP_TRY(hipGetLastError());
