@@ -69,7 +69,11 @@ def main(argv) -> int:
     flags = int(os.environ.get("LBM_FLAGS", lbm._capi.FLAG_EXACT_AVVELS))
     # LBM_RANK_GRID=PXxPY (PX * PY = the ranks): the tile (2-D) decomposition instead of the reference's row blocks (peer-to-peer loop)
     rank_grid = None
-    if os.environ.get("LBM_RANK_GRID"):
+    if os.environ.get("LBM_RANK_GRID") == "auto":             # lbm_choose_rank_grid: row blocks unless the grid is much wider than tall
+        rank_grid = lbm.choose_rank_grid(params, world, flags)
+        if rank_grid is not None:
+            exchange = "p2p"
+    elif os.environ.get("LBM_RANK_GRID"):
         try:
             rank_grid = tuple(int(v) for v in os.environ["LBM_RANK_GRID"].lower().split("x"))
             assert len(rank_grid) == 2 and rank_grid[0] * rank_grid[1] == world

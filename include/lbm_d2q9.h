@@ -154,6 +154,11 @@ typedef struct lbm_tile_layout {
 } lbm_tile_layout;
 int lbm_decompose_columns(int nx, int px, int* nx_local, int* displs);
 int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned flags, lbm_tile_layout* out);
+/* Row blocks or tiles for `nranks` ranks, by the measurements of DESIGN.md 6.5: the reference's row blocks unless the thinnest rank would
+ * have fewer than 128 rows and a rank holds at least 2^18 cells (row blocks of >= 128 rows beat tiles of the same cells at every size
+ * measured; thin AND large ones lose by 1.4 - 1.9 x); then the tile grid whose ranks recompute the smallest share of cells they do not
+ * own.  A function of p, nranks and flags only.  *px == 1: row blocks (lbm_create_rank); otherwise lbm_create_tile on *px x *py. */
+int lbm_choose_rank_grid(const lbm_params* p, int nranks, unsigned flags, int* px, int* py);
 /* obstacle_window: (ny_local + 2*ghost) rows of (nx_local + 2*ghost_x) ints — global rows y0-ghost .., global columns x0-ghost_x ..,
  * both wrapping periodically.  lbm_get_cells / lbm_set_cells / lbm_get_observables of such a context move its ny_local x nx_local
  * block; lbm_state_checksum covers the rank's columns of the rows asked for (the digests of all ranks still add up to the grid's). */

@@ -18,11 +18,11 @@ from .build import CLI as CLI_PATH
 from .build import build
 from .decks import Params, synthetic_obstacles, write_obstacles, write_synthetic_deck
 from .host import (NORTH, SOUTH, HaloExchange, P2PRing, Partition, RcclRing, Simulation, av_velocity_host, av_velocity_obs,
-                   count_free_cells, decompose, obstacle_window, plan_groups, plan_steps, rank_layout, tile_layout, read_obstacles, read_params, reynolds,
+                   count_free_cells, decompose, obstacle_window, plan_groups, plan_steps, rank_layout, tile_layout, choose_rank_grid, read_obstacles, read_params, reynolds,
                    run_partitioned, write_av_vels, write_final_state, write_final_state_obs)
 
 __all__ = [
-    "EXPORTS", "RCCL_EXPORTS", "P2P_EXPORTS", "P2PRing", "av_velocity_obs", "obstacle_window", "plan_groups", "plan_steps", "rank_layout", "tile_layout", "write_final_state_obs", "LIB_PATH", "LIB_RCCL_PATH", "load_rccl_library", "CLI_PATH", "LbmError", "load_library", "build", "Params", "synthetic_obstacles",
+    "EXPORTS", "RCCL_EXPORTS", "P2P_EXPORTS", "P2PRing", "av_velocity_obs", "obstacle_window", "plan_groups", "plan_steps", "rank_layout", "tile_layout", "choose_rank_grid", "write_final_state_obs", "LIB_PATH", "LIB_RCCL_PATH", "load_rccl_library", "CLI_PATH", "LbmError", "load_library", "build", "Params", "synthetic_obstacles",
     "write_obstacles", "write_synthetic_deck", "NORTH", "SOUTH", "HaloExchange", "Partition", "RcclRing", "Simulation",
     "av_velocity_host", "count_free_cells", "decompose", "read_obstacles", "read_params", "reynolds",
     "run_partitioned", "write_av_vels", "write_final_state", "checker", "decks",

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "lbm_create_rank": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_decompose_columns": (C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
     "lbm_tile_layout_of": (C.c_int, [_P(CParams), C.c_int, C.c_int, C.c_int, C.c_uint, _P(CTileLayout)]),
+    "lbm_choose_rank_grid": (C.c_int, [_P(CParams), C.c_int, C.c_uint, _P(C.c_int), _P(C.c_int)]),
     "lbm_create_tile": (C.c_int, [_P(_ctx), _P(CParams), C.c_int, _P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "lbm_tile_info": (C.c_int, [_ctx, _P(CTileLayout)]),
     "lbm_destroy": (C.c_int, [_ctx]),

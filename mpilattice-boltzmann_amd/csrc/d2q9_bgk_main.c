@@ -16,7 +16,7 @@
  * thread per rank drives its device, and the halos travel as direct peer-to-peer stores over xGMI
  * (include/lbm_d2q9_p2p.h).  The ranks' observables are gathered in rank order — the order in which the reference's
  * ranks append to final_state.dat (:1049-1057).
- * LBM_RANK_GRID=PXxPY (PX * PY = N) runs those N ranks as the tile (2-D) decomposition instead (lbm_create_tile): rank = ry * PX + rx owns a
+ * LBM_RANK_GRID=PXxPY (PX * PY = N; or `auto`: lbm_choose_rank_grid decides between rows and tiles) runs those N ranks as the tile (2-D) decomposition instead (lbm_create_tile): rank = ry * PX + rx owns a
  * block of columns of a block of rows; the reference's report discusses such a split for grids wider than tall and never built it. */
 #define _POSIX_C_SOURCE 200809L
 #define _DEFAULT_SOURCE
@@ -94,7 +94,7 @@ int main(int argc, char* argv[])
   double tic = 0.0, toc = 0.0, usrtim, systim, mlups;
   struct rusage ru;
   float free_cells_inv, av;
-  int ngpus;
+  int ngpus, tiled = 0;
   unsigned flags;
   size_t nx;
 
@@ -132,8 +132,13 @@ int main(int argc, char* argv[])
     const char* grid = getenv("LBM_RANK_GRID");
     lbm_tile_layout* tile = NULL;
     int r, q, t, most = 1, px = 0, py = 0;
+    if (grid && strcmp(grid, "auto") == 0) {                              /* the library's choice between row blocks and tiles */
+      if (lbm_choose_rank_grid(&params, ngpus, flags, &px, &py)) die(lbm_last_error(), __LINE__, __FILE__);
+      if (px == 1) grid = NULL;
+    }
     if (grid && *grid) {
-      if (sscanf(grid, "%dx%d", &px, &py) != 2 || px < 1 || py < 1 || px * py != ngpus) die("LBM_RANK_GRID: expected PXxPY with PX * PY = LBM_GPUS", __LINE__, __FILE__);
+      if (strcmp(grid, "auto") != 0 && (sscanf(grid, "%dx%d", &px, &py) != 2 || px < 1 || py < 1 || px * py != ngpus))
+        die("LBM_RANK_GRID: expected PXxPY with PX * PY = LBM_GPUS, or auto", __LINE__, __FILE__);
       tile = (lbm_tile_layout*)xmalloc(sizeof(lbm_tile_layout) * (size_t)ngpus);
     }
     if (ngpus > 64) die("LBM_GPUS: at most 64 ranks (MPI_PROCS, d2q9-bgk.c:67)", __LINE__, __FILE__);
@@ -164,6 +169,7 @@ int main(int argc, char* argv[])
       snprintf(budget, sizeof budget, "%d", 2 * most + 4);
       setenv("GPU_MAX_HW_QUEUES", budget, 0);
     }
+    tiled = tile != NULL;
     for (r = 0; r < ngpus && tile; ++r) {
       /* the block this rank needs: its rows and columns plus the ghost rows / columns around them, wrapping both ways */
       int rows, cols, i, j;
@@ -254,7 +260,7 @@ int main(int argc, char* argv[])
   printf("Elapsed system CPU time:\t%.6lf (s)\n", systim);
   mlups = (double)params.nx * params.ny * params.max_iters / (toc - tic) / 1e6;
   printf("MLUPS:\t\t\t\t%.1f (%d GPU%s%s)\n", mlups, ngpus > 1 ? ngpus : 1, ngpus > 1 ? "s, peer-to-peer halos" : "",
-         (ngpus > 1 && getenv("LBM_RANK_GRID") && *getenv("LBM_RANK_GRID")) ? ", tile decomposition" : "");
+         tiled ? ", tile decomposition" : "");
   printf("HBM roofline (108 B/cell-step @ 8.0 TB/s = 74074 MLUPS per GPU):\t%.1f %%\n",
          100.0 * mlups / (ngpus > 1 ? ngpus : 1) / (8.0e12 / 108.0 / 1e6));
 

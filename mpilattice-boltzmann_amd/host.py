@@ -113,6 +113,16 @@ def tile_layout(params: Params, px: int, py: int, rank: int, flags: int = 0) -> 
     return {name: int(getattr(lay, name)) for name, _ in _capi.CTileLayout._fields_}
 
 
+def choose_rank_grid(params: Params, nranks: int, flags: int = 0) -> Optional[tuple[int, int]]:
+    """`lbm_choose_rank_grid`: None for the reference's row blocks, or (px, py) for the tile decomposition — whichever leaves the ranks
+    the fewest cells to recompute (grids much wider than tall come out as tiles)."""
+    lib = _capi.load_library()
+    cp = _cparams(params)
+    px, py = C.c_int(0), C.c_int(0)
+    check(lib.lbm_choose_rank_grid(C.byref(cp), nranks, flags, C.byref(px), C.byref(py)))
+    return None if px.value == 1 else (px.value, py.value)
+
+
 def obstacle_window(obstacles: np.ndarray, layout: dict) -> np.ndarray:
     """The part of the global map one rank needs: its owned rows plus `ghost` rows below and above,
     wrapping periodically — what the root hands each rank instead of the reference's `MPI_Scatterv` of
@@ -739,7 +749,8 @@ class Simulation:
         hands each rank its window of rows (the reference's `MPI_Scatterv`, `d2q9-bgk.c:968-970`) and the
         free-cell count (`MPI_Bcast`, `:966`).
         rank_grid = (px, py): the tile (2-D) decomposition over px x py = size ranks (`tile_layout`) instead of the
-        reference's row blocks — peer-to-peer loop only; (1, 1) is a one-rank ring that exchanges with itself."""
+        reference's row blocks — peer-to-peer loop only; (1, 1) is a one-rank ring that exchanges with itself;
+        "auto": `choose_rank_grid` decides between row blocks and tiles."""
         if exchange not in EXCHANGES:
             raise ValueError(f"exchange must be one of {EXCHANGES}")
         self.params = params
@@ -758,6 +769,10 @@ class Simulation:
             raise ValueError("obstacles may only be None on ranks other than 0 of a distributed run")
         self.obstacles = obstacles          # whole map where this rank has it (rank 0 always), else None
         self.rank_grid = None
+        if isinstance(rank_grid, str):
+            if rank_grid != "auto":
+                raise ValueError("rank_grid is (px, py), None or \"auto\"")
+            rank_grid = choose_rank_grid(params, self.size, flags) if exchange in ("auto", "p2p") and not step_allreduce else None
         if rank_grid is not None:
             px, py = int(rank_grid[0]), int(rank_grid[1])
             if px < 1 or py < 1 or px * py != self.size:

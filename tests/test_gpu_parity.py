@@ -1415,6 +1415,26 @@ def test_cli_drives_a_tile_decomposition_from_one_process(lbm, digests, tmp_path
     assert bad.returncode != 0 and "LBM_RANK_GRID" in bad.stderr
 
 
+def test_cli_chooses_tiles_for_a_grid_much_wider_than_tall(lbm, tmp_path):
+    """LBM_RANK_GRID=auto (lbm_choose_rank_grid): a 8192 x 256 deck on 4 ranks — 64-row blocks of 512 K cells — runs as 4 x 1 tiles, the shipped
+    square deck as row blocks; either way the files equal a one-rank run's byte for byte."""
+    p = lbm.Params(8192, 256, 24, 10, 0.1, 0.005, 1.85)
+    assert lbm.choose_rank_grid(p, 4) == (4, 1)
+    ppath, opath = lbm.write_synthetic_deck(str(tmp_path), "8192x256", p, p=0.005, seed=7)
+    outs = {}
+    for tag, extra in (("one", {}), ("auto", dict(LBM_GPUS="4", LBM_DEVICES="0,0,0,0", LBM_RANK_GRID="auto", LBM_P2P_TIMEOUT_MS="20000"))):
+        d = tmp_path / tag
+        d.mkdir()
+        env = {k: v for k, v in os.environ.items() if k not in ("LBM_GPUS", "LBM_DEVICES", "LBM_RANK_GRID")}
+        env.update(extra)
+        r = subprocess.run([lbm.CLI_PATH, ppath, opath], cwd=d, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (r.stdout.splitlines(), sha256(d / "final_state.dat"), lbm.checker.load_av_vels(str(d / "av_vels.dat")))
+    assert "(4 GPUs, peer-to-peer halos, tile decomposition)" in outs["auto"][0][5]
+    assert outs["one"][0][1] == outs["auto"][0][1] and outs["one"][1] == outs["auto"][1]
+    assert np.allclose(outs["one"][2], outs["auto"][2], rtol=2e-7, atol=0)
+
+
 @pytest.mark.parametrize("devices", ["0,0", "0,1"])
 def test_cli_ranks_of_one_process_on_the_tall_geometry(lbm, tmp_path, devices):
     """The single-process multi-device host (LBM_GPUS=N, one context per rank in ONE process: the reference's `mpirun -np N`,

@@ -697,6 +697,24 @@ def test_tile_layout_is_one_decision_for_all_ranks(lbm, monkeypatch):
         lbm.tile_layout(lbm.Params(512, 256, 10, 10, 0.1, 0.005, 1.85), 2, 2, 4)
 
 
+def test_rank_grid_choice_follows_the_measurements(lbm):
+    """lbm_choose_rank_grid: the reference's row blocks (d2q9-bgk.c:834-862) wherever they measured faster — every deck whose ranks keep >= 128
+    rows, and thin but small ones — and tiles for the grids much wider than tall that SURVEY.md section 8(f) row 3 names (the pairs
+    behind each line); the same answer on every rank (a function of p, nranks, flags)."""
+    P = lambda nx, ny: lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
+    rows = [(8192, 8192, 8), (8192, 8192, 2), (1024, 1024, 8), (1024, 1024, 16), (2048, 512, 8), (2048, 512, 4), (128, 128, 4), (8192, 8192, 1), (16384, 1024, 8)]
+    for nx, ny, n in rows:
+        assert lbm.choose_rank_grid(P(nx, ny), n) is None, (nx, ny, n)
+    assert lbm.choose_rank_grid(P(16384, 512), 8) == (8, 1)          # 64-row blocks of 1 M cells: 13.2 us/step against 9.7 as 2048 x 512
+    assert lbm.choose_rank_grid(P(32768, 256), 8) == (8, 1)          # 32-row blocks: 18.3 against 10.6
+    assert lbm.choose_rank_grid(P(65536, 128), 8) == (8, 1)          # 16-row blocks (one-step loop): 21.9 against 11.8
+    px, py = lbm.choose_rank_grid(P(16384, 512), 16)
+    assert px * py == 16 and px > 1 and lbm.tile_layout(P(16384, 512), px, py, 0)["ny_local"] >= 128
+    assert lbm.choose_rank_grid(P(16384, 512), 8, lbm._capi.FLAG_ONE_STEP) is None       # no K-step mode, no tiles
+    with pytest.raises(lbm.LbmError):
+        lbm.choose_rank_grid(P(16384, 512), 0)
+
+
 def test_tile_obstacle_window_wraps_in_both_directions(lbm):
     p = lbm.Params(512, 256, 10, 10, 0.1, 0.005, 1.85)
     obst = np.arange(256 * 512, dtype=np.int32).reshape(256, 512)
