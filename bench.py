@@ -88,6 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--rank-grid", default="",
                     help="PXxPY: headline over the tile (2-D) decomposition on PX x PY = N ranks instead of the reference's row blocks (peer-to-peer "
                          "loop only; with --ring: 1x1, a rank that is its own neighbour in every direction)")
+    ap.add_argument("--column-block", action="store_true",
+                    help="with --ring --rank-grid 1x1: the ring stands for a block of a PX x 1 tiling (a column block: no ghost rows, its rows wrap inside "
+                         "the launch, an exchange is the column push alone) instead of a block of any tiling (ghost rows, row push onto itself)")
     ap.add_argument("--no-power", action="store_true", help="do not sample the card's socket power / shader clock (hwmon files) during the headline")
     ap.add_argument("--no-phases", action="store_true", help="skip the profiled extra repetition behind `phases` / the per-launch roofline timing")
     ap.add_argument("--secondary-steps", type=int, default=0, help="steps of the 1024x1024 deck (default: its own 20 000)")
@@ -624,6 +627,9 @@ def main() -> int:
             if rank == 0:
                 emit({"error": f"--rank-grid {args.rank_grid}: expected PXxPY with PX * PY = {world} ranks (and --ring on one GPU)", "n_gpus": world})
             return 2
+
+    if head_grid == (1, 1) and not args.column_block:
+        os.environ["LBM_TUNE_TILE_GHOST_ROWS"] = "1"       # read by lbm_tile_layout_of: the one rank is its own south / north neighbour through the row push
 
     def default_grid(n: int):
         """The rank grid of the `p2p_tiles` variant: as square as n allows, the longer side along x (8 -> 4 x 2)."""

@@ -149,8 +149,10 @@ int lbm_create_rank(lbm_ctx** ctx, const lbm_params* p, int free_cells, const in
 typedef struct lbm_tile_layout {
   int px, py, rx, ry;               /* the rank grid and this rank's place in it */
   int x0, nx_local, y0, ny_local;   /* columns [x0, x0+nx_local) of rows [y0, y0+ny_local) belong to the rank */
-  int macro_k, ghost, group;        /* as lbm_layout */
+  int macro_k, ghost, group;        /* as lbm_layout: `ghost` = the steps between two exchanges */
   int ghost_x;                      /* ghost columns kept on each side: ghost rounded up to even */
+  int ghost_y;                      /* ghost ROWS kept on each side: ghost — or 0 for column blocks (py == 1: the rank owns every row, its
+                                       launches wrap in y like a whole grid's and an exchange is the column push alone) */
 } lbm_tile_layout;
 int lbm_decompose_columns(int nx, int px, int* nx_local, int* displs);
 int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned flags, lbm_tile_layout* out);
@@ -159,7 +161,7 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
  * measured; thin AND large ones lose by 1.4 - 1.9 x); then the tile grid whose ranks recompute the smallest share of cells they do not
  * own.  A function of p, nranks and flags only.  *px == 1: row blocks (lbm_create_rank); otherwise lbm_create_tile on *px x *py. */
 int lbm_choose_rank_grid(const lbm_params* p, int nranks, unsigned flags, int* px, int* py);
-/* obstacle_window: (ny_local + 2*ghost) rows of (nx_local + 2*ghost_x) ints — global rows y0-ghost .., global columns x0-ghost_x ..,
+/* obstacle_window: (ny_local + 2*ghost_y) rows of (nx_local + 2*ghost_x) ints — global rows y0-ghost_y .., global columns x0-ghost_x ..,
  * both wrapping periodically.  lbm_get_cells / lbm_set_cells / lbm_get_observables of such a context move its ny_local x nx_local
  * block; lbm_state_checksum covers the rank's columns of the rows asked for (the digests of all ranks still add up to the grid's). */
 int lbm_create_tile(lbm_ctx** ctx, const lbm_params* p, int free_cells, const int* obstacle_window,

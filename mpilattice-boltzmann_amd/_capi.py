@@ -40,7 +40,7 @@ class CLayout(C.Structure):
 class CTileLayout(C.Structure):
     """struct lbm_tile_layout."""
 
-    _fields_ = [(n, C.c_int) for n in ("px", "py", "rx", "ry", "x0", "nx_local", "y0", "ny_local", "macro_k", "ghost", "group", "ghost_x")]
+    _fields_ = [(n, C.c_int) for n in ("px", "py", "rx", "ry", "x0", "nx_local", "y0", "ny_local", "macro_k", "ghost", "group", "ghost_x", "ghost_y")]
 
 
 _P = C.POINTER

@@ -175,11 +175,11 @@ int main(int argc, char* argv[])
       int rows, cols, i, j;
       int* window;
       if (lbm_tile_layout_of(&params, px, py, r, flags, &tile[r])) die(lbm_last_error(), __LINE__, __FILE__);
-      rows = tile[r].ny_local + 2 * tile[r].ghost;
+      rows = tile[r].ny_local + 2 * tile[r].ghost_y;
       cols = tile[r].nx_local + 2 * tile[r].ghost_x;
       window = (int*)xmalloc(sizeof(int) * (size_t)rows * (size_t)cols);
       for (i = 0; i < rows; ++i) {
-        int g = (tile[r].y0 - tile[r].ghost + i) % params.ny;
+        int g = (tile[r].y0 - tile[r].ghost_y + i) % params.ny;
         if (g < 0) g += params.ny;
         for (j = 0; j < cols; ++j) {
           int x = (tile[r].x0 - tile[r].ghost_x + j) % params.nx;

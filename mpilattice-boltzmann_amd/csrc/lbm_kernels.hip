@@ -117,6 +117,10 @@ struct lbm_ctx {
   // ghost_x ghost columns on each side and p.nx is THEIR width (nxl + 2 * ghost_x): kernels, masks and row arithmetic all work on
   // storage rows; nx_global is the grid's.  Everywhere else ghost_x = 0, nxl = nx_global = p.nx.
   int ghost_x = 0, x0 = 0, nxl = 0, nx_global = 0;
+  // Storage rows kept below / above the owned rows: `ghost` for every K-step partition — except a tile rank that owns ALL rows of the grid
+  // (py = 1: a column block), which keeps none: its launches wrap in y as a whole grid's do, only columns are exchanged.  `ghost` stays the
+  // number of steps between two exchanges either way.
+  int ghost_rows = 0;
   int tiles_px = 1, tiles_py = 1, tile_rx = 0, tile_ry = 0;
   unsigned long long* ready_ptr[4] = {nullptr, nullptr, nullptr, nullptr};   // peer-to-peer loop: the next launch_multi says "ready for epoch ready_epoch" to the
   unsigned long long ready_epoch = 0;                       // neighbours (MultiArgs::ready) and waits for theirs; cleared by that launch
@@ -345,7 +349,8 @@ void launch_multi_k(int blocks, hipStream_t s, const MultiArgs& a, int terms, in
 
 // Tiles of a launch that makes `k` steps on the owned rows and `ext` more rows on each side (ext > 0: a launch of a partitioned
 // run that is followed by `ext` more steps before the next halo exchange): the tile height depends on k (kernels/multi.h multi_ty).
-int multi_tile_rows(const lbm_ctx* c, int k, int ext = 0) { return (c->nyl + 2 * ext + multi_ty(k, c->multi_geom) - 1) / multi_ty(k, c->multi_geom); }
+int ext_rows(const lbm_ctx* c, int ext) { return c->ghost_rows > 0 ? ext : 0; }
+int multi_tile_rows(const lbm_ctx* c, int k, int ext = 0) { return (c->nyl + 2 * ext_rows(c, ext) + multi_ty(k, c->multi_geom) - 1) / multi_ty(k, c->multi_geom); }
 int multi_tiles_for(const lbm_ctx* c, int k, int ext = 0) { return c->multi_tiles_x * multi_tile_rows(c, k, ext); }
 
 // One launch of lbm_multi_kernel over the tile ranges [t0, t0+n0) and [t1, t1+n1): `ksteps` steps of the owned rows and `ext`
@@ -357,12 +362,13 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   a.src = c->grid[c->cur]; a.dst = c->grid[c->cur ^ 1];
   for (int k = 0; k < 9; ++k) { a.srck[k] = a.src + k * c->ps; a.dstk[k] = a.dst + k * c->ps; }
   a.mask = c->mask; a.ps = c->ps; a.nx = c->p.nx;
-  a.row_first = c->ghost - ext; a.rows_compute = c->nyl + 2 * ext; a.rows_storage = c->nyl + 2 * c->ghost;
-  a.count_first = c->ghost; a.count_end = c->ghost + c->nyl;
+  const int ext_y = ext_rows(c, ext);                           // ghost rows this launch advances (none where the rows wrap)
+  a.row_first = c->ghost_rows - ext_y; a.rows_compute = c->nyl + 2 * ext_y; a.rows_storage = c->nyl + 2 * c->ghost_rows;
+  a.count_first = c->ghost_rows; a.count_end = c->ghost_rows + c->nyl;
   a.cx0 = c->ghost_x; a.cx1 = c->ghost_x + c->nxl;
   a.keep_x0 = std::max(0, (c->ghost_x - ext) & ~1); a.keep_x1 = std::min(c->p.nx, (c->ghost_x + c->nxl + ext + 1) & ~1);
-  a.y_periodic = c->self_periodic ? 1 : 0;
-  a.y0_global = c->y0 - ext; a.ny_global = c->p.ny;          // global row of storage row row_first
+  a.y_periodic = (c->self_periodic || (c->ghost > 0 && c->ghost_rows == 0)) ? 1 : 0;
+  a.y0_global = c->y0 - ext_y; a.ny_global = c->p.ny;        // global row of storage row row_first
   a.tiles_x = c->multi_tiles_x;
   a.tile_begin = t0; a.tile_count = n0; a.tile_begin2 = t1; a.tile_count2 = n1;
   a.ntiles_total = multi_tiles_for(c, ksteps, ext);
@@ -480,7 +486,7 @@ int begin_run(lbm_ctx* c, int n_steps, hipStream_t s)
     // accelerate_flow of step 0 (d2q9-bgk.c:345-348); later steps get it from the kernel epilogue
     const int nx = c->p.nx;
     hipLaunchKernelGGL(lbm_accelerate_kernel, dim3((c->nxl + 255) / 256), dim3(256), 0, s, c->grid[c->cur], c->ps,
-                       c->mask, nx, c->ghost + c->accel_row, c->accel_w1, c->accel_w2, c->ghost_x, c->nxl);
+                       c->mask, nx, c->ghost_rows + c->accel_row, c->accel_w1, c->accel_w2, c->ghost_x, c->nxl);
     HIP_TRY(hipGetLastError());
   }
   c->ev_valid = false;
@@ -690,7 +696,7 @@ static void pack_obstacle_bits(std::vector<uint32_t>& bits, int rows, int nx, Ro
 // ((ny_local + 2*forced_k)*nx: the rows around the partition only, lbm_create_rank); both null = no ghost
 // rows possible.  forced_k < 0: K-step mode and K decided from this partition's own shape
 // (lbm_create_global); >= 0: decided by the caller for the whole run (lbm_rank_layout).
-struct TileSpec { int px, py, rx, ry, x0, nxl, ghost_x, nx_global; };    // lbm_create_tile: `p->nx` is then the storage row width nxl + 2 ghost_x
+struct TileSpec { int px, py, rx, ry, x0, nxl, ghost_x, nx_global, ghost_rows; };    // lbm_create_tile: `p->nx` is then the storage row width nxl + 2 ghost_x
 
 static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const int* obstacles_rows,
                        const int* obstacles_global, const int* obstacles_window, int forced_k, int forced_ghost, int y0, int ny_local,
@@ -745,13 +751,14 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
       return 1;
     }
     c->multi_K = forced_k; c->ghost = forced_ghost;
+    c->ghost_rows = (tile && !tile->ghost_rows) ? 0 : forced_ghost;
     c->group_max = macro_group_for(forced_k, forced_ghost);
   } else if (forced_k < 0 && !self_periodic && obstacles_global && macro_eligible(p, ny_local, flags)) {
     const int k = macro_k_for(c->ncells);
-    if (k > 0) { c->multi_K = k; c->ghost = macro_ghost_for(k, p->nx, ny_local, ny_local); c->group_max = macro_group_for(k, c->ghost); }
+    if (k > 0) { c->multi_K = k; c->ghost = c->ghost_rows = macro_ghost_for(k, p->nx, ny_local, ny_local); c->group_max = macro_group_for(k, c->ghost); }
   }
   c->multi_tail4 = tune_env("LBM_TUNE_MULTI_TAIL4", 1) != 0;
-  c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost);
+  c->ncells_storage = static_cast<size_t>(p->nx) * (ny_local + 2 * c->ghost_rows);
   c->ps = plane_stride_floats(c->ncells_storage);
   c->grid_floats = 9 * c->ps + 128;
   // non-temporal output stores once the two grids no longer fit the 256 MiB Infinity Cache
@@ -802,7 +809,7 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   const size_t mwords = (c->ncells_storage + 31) / 32 + 4;
   std::vector<uint32_t> bits(mwords, 0u);
   {
-    const int nx = p->nx, ny = p->ny, ghost = c->ghost;
+    const int nx = p->nx, ny = p->ny, ghost = c->ghost_rows;
     const int rows = ny_local + 2 * ghost;
     if (ghost == 0) pack_obstacle_bits(bits, rows, nx, [&](int r) { return obstacles_rows + static_cast<size_t>(r) * nx; });
     else if (obstacles_window) pack_obstacle_bits(bits, rows, nx, [&](int r) { return obstacles_window + static_cast<size_t>(r) * nx; });
@@ -849,14 +856,14 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
   c->tile_kernel = self_periodic && c->n_tiles > 0 &&
                    c->ncells <= static_cast<size_t>(tune_env("LBM_TUNE_TILE_MAX", 131072));  // us/step here vs lbm_multi_kernel<3>: 256x256 1.9 / 3.1, 512x256 2.8 / 3.2, 384x384 3.6 / 3.2, 512x512 4.5 / 3.3
   if (c->ghost > 0) {
-    const size_t pack_floats = static_cast<size_t>(2) * 9 * c->ghost * p->nx;
+    const size_t pack_floats = static_cast<size_t>(2) * 9 * std::max(c->ghost_rows, 1) * p->nx;
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
     c->multi_geom = pick_geom(c->ncells);
     c->multi_tx = geom_tx(c->multi_geom);
     HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
-    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + 2 * c->ghost + kMinMultiTY - 1) / kMinMultiTY) + 1);
+    c->partials_cap = std::max(c->partials_cap, kMaxMultiSteps * c->multi_tiles_x * ((ny_local + 2 * c->ghost_rows + kMinMultiTY - 1) / kMinMultiTY) + 1);
   } else if (!c->tile_kernel && self_periodic && fits_u32 && p->nx < (1 << 23) &&      // (24-bit row multiplies in lbm_multi_kernel)
              ((p->nx % kMTX == 0 && ny_local % kMTY == 0) || (p->nx % 2 == 0 && p->nx >= 2 * kMTX && ny_local >= 2 * kMTY))) {
     // grids tiled exactly by 64x16, or any even nx >= 128 with ny >= 32, where the last tile column / row
@@ -995,13 +1002,17 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
   lbm_params narrow = *p, wide = *p;
   narrow.nx = clo + 2 * ghost_x; wide.nx = chi + 2 * ghost_x;
   if (k <= 0 || !macro_eligible(&narrow, rlo, flags) || !macro_eligible(&wide, rhi, flags) || !macro_eligible(&narrow, rhi, flags) || !macro_eligible(&wide, rlo, flags) ||
-      clo < ghost_x || rlo < ghost) {
+      clo < ghost_x || (py > 1 && rlo < ghost)) {
     lbm_internal::set_error("lbm_tile_layout_of: the tile decomposition runs in K-step mode only: every rank needs >= 32 rows, an even number of columns with "
                             "at least 128 storage columns (owned + ghost) and LBM_FLAG_ONE_STEP clear — use the row decomposition (lbm_rank_layout)");
     return 1;
   }
   out->macro_k = k; out->ghost = ghost; out->ghost_x = ghost_x;
   out->group = macro_group_for(k, ghost);
+  // column blocks (py = 1: every rank owns all rows) keep no ghost rows: their launches wrap in y like a whole grid's, and an exchange is the
+  // column push alone.  LBM_TUNE_TILE_GHOST_ROWS=1 keeps them (a 1 x 1 ring then stands for a block of ANY tiling: the rank is its own south
+  // and north neighbour through the row push, as it is its own west and east one)
+  out->ghost_y = (py == 1 && !tune_env("LBM_TUNE_TILE_GHOST_ROWS", 0)) ? 0 : ghost;
   return 0;
 }
 
@@ -1049,8 +1060,8 @@ int lbm_create_tile(lbm_ctx** out, const lbm_params* p, int free_cells, const in
   if (lbm_tile_layout_of(p, px, py, rank, flags, &lay)) return 1;
   lbm_params local = *p;
   local.nx = lay.nx_local + 2 * lay.ghost_x;                                           // the storage row: what every kernel works on
-  const TileSpec tile{px, py, lay.rx, lay.ry, lay.x0, lay.nx_local, lay.ghost_x, p->nx};
-  const int* rows = obstacle_window + static_cast<size_t>(lay.ghost) * local.nx;      // the owned rows inside the window
+  const TileSpec tile{px, py, lay.rx, lay.ry, lay.x0, lay.nx_local, lay.ghost_x, p->nx, lay.ghost_y};
+  const int* rows = obstacle_window + static_cast<size_t>(lay.ghost_y) * local.nx;    // the owned rows inside the window
   return create_impl(out, &local, free_cells, rows, nullptr, obstacle_window, lay.macro_k, lay.ghost, lay.y0, lay.ny_local, device,
                      flags | LBM_FLAG_FORCE_HALO, &tile);
 }
@@ -1062,6 +1073,7 @@ int lbm_tile_info(const lbm_ctx* c, lbm_tile_layout* out)
   out->px = c->tiles_px; out->py = c->tiles_py; out->rx = c->tile_rx; out->ry = c->tile_ry;
   out->x0 = c->x0; out->nx_local = c->nxl; out->y0 = c->y0; out->ny_local = c->nyl;
   out->macro_k = c->ghost > 0 ? c->multi_K : 0; out->ghost = c->ghost; out->ghost_x = c->ghost_x; out->group = c->group_max;
+  out->ghost_y = c->ghost_rows;
   return 0;
 }
 
@@ -1196,7 +1208,7 @@ int lbm_get_cells(lbm_ctx* c, float* cells_aos)
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * n));
   const int blocks = static_cast<int>((n + 255) / 256);
   hipLaunchKernelGGL(lbm_soa_to_aos_kernel, dim3(blocks), dim3(256), 0, c->stream,
-                     c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, tmp, c->ps, owned_cells(c), col_window(c));
+                     c->grid[c->cur] + static_cast<size_t>(c->ghost_rows) * c->p.nx, tmp, c->ps, owned_cells(c), col_window(c));
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(cells_aos, tmp, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1216,7 +1228,7 @@ int lbm_set_cells(lbm_ctx* c, const float* cells_aos)
   if (e == hipSuccess) {
     const int blocks = static_cast<int>((n + 255) / 256);
     hipLaunchKernelGGL(lbm_aos_to_soa_kernel, dim3(blocks), dim3(256), 0, c->stream, tmp,
-                       c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps, owned_cells(c), col_window(c));
+                       c->grid[c->cur] + static_cast<size_t>(c->ghost_rows) * c->p.nx, c->ps, owned_cells(c), col_window(c));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1236,7 +1248,7 @@ int lbm_get_observables(lbm_ctx* c, float* obs)
   float* tmp = nullptr;
   HIP_TRY(hipMalloc(&tmp, sizeof(float) * 4 * chunk));
   hipError_t e = hipSuccess;
-  const float* owned = c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx;
+  const float* owned = c->grid[c->cur] + static_cast<size_t>(c->ghost_rows) * c->p.nx;
   for (size_t c0 = 0; c0 < total && e == hipSuccess; c0 += chunk) {
     const size_t n = std::min(chunk, total - c0);
     hipLaunchKernelGGL(lbm_observables_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
@@ -1259,7 +1271,7 @@ int lbm_state_checksum(lbm_ctx* c, int y_begin, int y_end, unsigned long long* d
   HIP_TRY(hipMalloc(&dev, sizeof *dev));
   const size_t nx = static_cast<size_t>(c->p.nx);
   const size_t n = static_cast<size_t>(y_end - y_begin) * c->nxl;
-  const size_t c0 = (static_cast<size_t>(c->ghost) + static_cast<size_t>(y_begin - c->y0)) * nx;
+  const size_t c0 = (static_cast<size_t>(c->ghost_rows) + static_cast<size_t>(y_begin - c->y0)) * nx;
   hipError_t e = hipMemsetAsync(dev, 0, sizeof *dev, c->stream);
   if (e == hipSuccess && n > 0) {
     const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 4096));
@@ -1284,8 +1296,8 @@ int lbm_av_velocity_sum(lbm_ctx* c, double* tot_u)
   // owned rows only; in K-step mode they start ghost rows in: bit offset ghost*nx of the bitfield (any value:
   // nx = 130, K = 3 gives 390)
   hipLaunchKernelGGL(lbm_av_velocity_kernel, dim3(blocks), dim3(kBlock), 0, c->stream,
-                     c->grid[c->cur] + static_cast<size_t>(c->ghost) * c->p.nx, c->ps,
-                     c->mask, static_cast<size_t>(c->ghost) * c->p.nx, owned_cells(c), part, col_window(c));
+                     c->grid[c->cur] + static_cast<size_t>(c->ghost_rows) * c->p.nx, c->ps,
+                     c->mask, static_cast<size_t>(c->ghost_rows) * c->p.nx, owned_cells(c), part, col_window(c));
   std::vector<double> host(blocks);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(host.data(), part, sizeof(double) * blocks, hipMemcpyDeviceToHost, c->stream);
@@ -1487,12 +1499,15 @@ struct MacroRows { int bottom_edge_rows, interior_rows, top_edge_rows, left_cols
 static MacroRows macro_rows(const lbm_ctx* c, int k, int ext = 0)
 {
   const int ty = multi_ty(k, c->multi_geom);
-  const int first = c->ghost - ext, rows = c->nyl + 2 * ext;
+  const int ext_y = ext_rows(c, ext);
+  const int first = c->ghost_rows - ext_y, rows = c->nyl + 2 * ext_y;
   const int nty = (rows + ty - 1) / ty;
-  const int lo = c->ghost, hi = c->ghost + c->nyl;                // the owned rows [lo, hi)
+  const int lo = c->ghost_rows, hi = c->ghost_rows + c->nyl;      // the owned rows [lo, hi)
   int b = 0, t = 0;
-  while (b < nty && first + b * ty - k < lo) ++b;
-  while (t < nty - b && std::min(first + (nty - t) * ty, first + rows) - 1 + k >= hi) ++t;
+  if (c->ghost_rows > 0) {                                        // (a column block wraps in y: no tile row reads an exchanged row)
+    while (b < nty && first + b * ty - k < lo) ++b;
+    while (t < nty - b && std::min(first + (nty - t) * ty, first + rows) - 1 + k >= hi) ++t;
+  }
   int l = 0, r = 0;
   if (c->ghost_x > 0) {
     const int tx = c->multi_tx, ntx = c->multi_tiles_x, reach = 2 * (k - 1) + 1;

@@ -44,6 +44,7 @@ struct P2PBlob {                       // what every rank tells every other rank
   int32_t pid, device, nranks, rank;
   int32_t nx, ny, y0, nyl, ghost, K, cur, ipc_ok, group;      // nx: the GLOBAL grid width
   int32_t w, x0, nxl, ghost_x, px, py;                         // storage row width; tile decomposition: the rank's columns and the rank grid (1 x nranks otherwise)
+  int32_t ghost_rows;                                          // storage rows below / above the owned ones (`ghost`; 0 for the column blocks of a px x 1 tiling)
   uint64_t ps, window_bytes, reduce_cap;
   uint64_t grid_ptr[2], window_ptr;    // raw device pointers: valid inside the exporting process
   hipIpcMemHandle_t grid_h[2], window_h;
@@ -181,13 +182,13 @@ int p2p_push_cols(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s)
   a.src = c->grid[g]; a.ps = c->ps; a.src_w = c->p.nx;
   // west neighbour: the first k of its EAST ghost columns; east neighbour: the last k of its west ghost columns (its rows are mine:
   // the same y0, the same ghost rows)
-  a.dst[0] = pw.grid_alloc[g] + 64 + static_cast<size_t>(pw.blob.ghost) * pw.blob.w + (pw.blob.ghost_x + pw.blob.nxl);
-  a.dst[1] = pe.grid_alloc[g] + 64 + static_cast<size_t>(pe.blob.ghost) * pe.blob.w + (pe.blob.ghost_x - k);
+  a.dst[0] = pw.grid_alloc[g] + 64 + static_cast<size_t>(pw.blob.ghost_rows) * pw.blob.w + (pw.blob.ghost_x + pw.blob.nxl);
+  a.dst[1] = pe.grid_alloc[g] + 64 + static_cast<size_t>(pe.blob.ghost_rows) * pe.blob.w + (pe.blob.ghost_x - k);
   a.dst_ps[0] = pw.blob.ps; a.dst_ps[1] = pe.blob.ps;
   a.dst_w[0] = pw.blob.w; a.dst_w[1] = pe.blob.w;
   a.src_col[0] = gx;                    // my first k owned columns
   a.src_col[1] = gx + c->nxl - k;       // my last k owned columns
-  a.row0 = c->ghost; a.nrows = c->nyl; a.k = k;
+  a.row0 = c->ghost_rows; a.nrows = c->nyl; a.k = k;
   a.flag[0] = &header_of(pw.window)->halo_flag_x[1];      // my columns arrive from the west neighbour's EAST
   a.flag[1] = &header_of(pe.window)->halo_flag_x[0];
   a.parity_word[0] = &header_of(pw.window)->halo_parity_x[2 * 1 + (epoch & 1ull)];
@@ -215,6 +216,7 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
 {
   lbm_ctx* c = t->ctx;
   if (t->tiles && p2p_push_cols(t, epoch, k, s)) return 1;
+  if (c->ghost_rows == 0) return 0;      // a column block (px x 1 tiling): its rows wrap inside the launch, the column push is the whole exchange
   const P2PPeer& ps = t->peers[t->south];
   const P2PPeer& pn = t->peers[t->north];
   const int nx = c->p.nx, g = c->cur;
@@ -223,12 +225,12 @@ int p2p_push(lbm_p2p* t, unsigned long long epoch, int k, hipStream_t s, bool ex
   a.ps = c->ps;
   // south neighbour: the first k of its TOP ghost rows (storage row ghost + nyl of ITS layout); north neighbour: the
   // last k of its bottom ghost rows (storage rows ghost - k .. ghost - 1)
-  a.dst[0] = ps.grid_alloc[g] + 64 + static_cast<size_t>(ps.blob.ghost + ps.blob.nyl) * nx;
-  a.dst[1] = pn.grid_alloc[g] + 64 + static_cast<size_t>(pn.blob.ghost - k) * nx;
+  a.dst[0] = ps.grid_alloc[g] + 64 + static_cast<size_t>(ps.blob.ghost_rows + ps.blob.nyl) * nx;
+  a.dst[1] = pn.grid_alloc[g] + 64 + static_cast<size_t>(pn.blob.ghost_rows - k) * nx;
   a.dst_ps[0] = ps.blob.ps;
   a.dst_ps[1] = pn.blob.ps;
-  a.src_row[0] = static_cast<size_t>(c->ghost);                  // my first k owned rows
-  a.src_row[1] = static_cast<size_t>(c->ghost + c->nyl - k);     // my last k owned rows
+  a.src_row[0] = static_cast<size_t>(c->ghost_rows);             // my first k owned rows
+  a.src_row[1] = static_cast<size_t>(c->ghost_rows + c->nyl - k);   // my last k owned rows
   a.nfloats = k * nx;
   a.flag[0] = &header_of(ps.window)->halo_flag[1];       // my rows arrive from the south neighbour's NORTH
   a.flag[1] = &header_of(pn.window)->halo_flag[0];
@@ -475,6 +477,7 @@ int lbm_p2p_handle(lbm_p2p* t, void* blob_out)
   b.magic = kP2PMagic; b.version = LBM_ABI_VERSION;
   b.pid = static_cast<int32_t>(getpid()); b.device = c->device; b.nranks = t->nranks; b.rank = t->rank;
   b.nx = c->nx_global; b.ny = c->p.ny; b.y0 = c->y0; b.nyl = c->nyl; b.ghost = c->ghost; b.K = c->multi_K; b.cur = c->cur; b.group = c->group_max;
+  b.ghost_rows = c->ghost_rows;
   b.w = c->p.nx; b.x0 = c->x0; b.nxl = c->nxl; b.ghost_x = c->ghost_x; b.px = t->tiles ? c->tiles_px : 1; b.py = t->tiles ? c->tiles_py : t->nranks;
   b.ps = c->ps; b.window_bytes = t->window_bytes; b.reduce_cap = t->reduce_cap;
   // IPC handles serve peers in OTHER processes; contexts of one process use the raw pointers, so a
@@ -516,7 +519,7 @@ int lbm_p2p_connect(lbm_p2p* t, const void* blobs)
       return 1;
     }
     if (b.nx != c->nx_global || b.ny != c->p.ny || b.K != c->multi_K || b.ghost != c->ghost || b.group != c->group_max || b.cur != c->cur || b.reduce_cap != t->reduce_cap ||
-        b.ghost_x != c->ghost_x || b.px != (t->tiles ? c->tiles_px : 1) || b.py != (t->tiles ? c->tiles_py : t->nranks)) {
+        b.ghost_x != c->ghost_x || b.ghost_rows != c->ghost_rows || b.px != (t->tiles ? c->tiles_px : 1) || b.py != (t->tiles ? c->tiles_py : t->nranks)) {
       lbm_internal::set_error("lbm_p2p_connect: rank " + std::to_string(r) + " runs a different layout (nx " + std::to_string(b.nx) + ", ny " +
                               std::to_string(b.ny) + ", K " + std::to_string(b.K) + ", " + std::to_string(b.ghost) + " ghost rows, " + std::to_string(b.group) +
                               " launches per exchange) than rank " + std::to_string(t->rank) + " (K " + std::to_string(c->multi_K) + ", " + std::to_string(c->ghost) +
@@ -741,8 +744,8 @@ int lbm_p2p_run(lbm_p2p* t, int n_steps, double* tot_u_per_step)
       if (t->edge_stream) {
         // the rows to push are the last launch's: its edge rows when the group was one launch and those tile rows hold all
         // next.total rows of either side (then the push need not wait for the interior launch); else the compute stream's
-        const bool edge_rows_suffice = g.n == 1 && !t->tiles && (c->ghost - g.ext(0)) + rows.bottom_edge_rows * multi_ty(g.k[0], c->multi_geom) >= c->ghost + next.total &&
-                                       (c->ghost - g.ext(0)) + (rows.bottom_edge_rows + rows.interior_rows) * multi_ty(g.k[0], c->multi_geom) <= c->ghost + c->nyl - next.total;
+        const bool edge_rows_suffice = g.n == 1 && !t->tiles && (c->ghost_rows - g.ext(0)) + rows.bottom_edge_rows * multi_ty(g.k[0], c->multi_geom) >= c->ghost_rows + next.total &&
+                                       (c->ghost_rows - g.ext(0)) + (rows.bottom_edge_rows + rows.interior_rows) * multi_ty(g.k[0], c->multi_geom) <= c->ghost_rows + c->nyl - next.total;
         if (!edge_rows_suffice) { P2P_RUN_TRY(hipStreamWaitEvent(es, t->interior_done, 0)); es_has_waited = true; }
       }
       P2PSpan sp;
@@ -830,7 +833,8 @@ int lbm_p2p_describe(const lbm_p2p* t, char* text, size_t len)
   int n = std::snprintf(text, len, "window %s; neighbours %s; schedule %s; K %d; ghost rows %d; launches per exchange %d", t->window_kind, reach,
                         t->edge_stream ? "edge stream" : "serial", t->ctx->multi_K, t->ctx->ghost, t->ctx->group_max);
   if (t->tiles && n > 0 && static_cast<size_t>(n) < len)
-    std::snprintf(text + n, len - n, "; tiles %d x %d; ghost columns %d", t->ctx->tiles_px, t->ctx->tiles_py, t->ctx->ghost_x);
+    std::snprintf(text + n, len - n, "; tiles %d x %d; ghost columns %d%s", t->ctx->tiles_px, t->ctx->tiles_py, t->ctx->ghost_x,
+                  t->ctx->ghost_rows == 0 ? "; rows wrap in the launch" : "");
   return 0;
 }
 

@@ -129,7 +129,8 @@ def obstacle_window(obstacles: np.ndarray, layout: dict) -> np.ndarray:
     the owned rows alone (`d2q9-bgk.c:968-970`).  A rank of the tile decomposition (`tile_layout`) gets
     its columns plus `ghost_x` on each side of those rows."""
     ny, nx = obstacles.shape
-    rows = np.arange(layout["y0"] - layout["ghost"], layout["y0"] + layout["ny_local"] + layout["ghost"]) % ny
+    gy = layout.get("ghost_y", layout["ghost"])          # (column blocks of the tile decomposition keep no ghost rows)
+    rows = np.arange(layout["y0"] - gy, layout["y0"] + layout["ny_local"] + gy) % ny
     if "ghost_x" not in layout:
         return np.ascontiguousarray(obstacles[rows], dtype=np.int32)
     cols = np.arange(layout["x0"] - layout["ghost_x"], layout["x0"] + layout["nx_local"] + layout["ghost_x"]) % nx
@@ -214,8 +215,8 @@ class Partition:
         if tile_of is not None:
             rank, px, py = tile_of
             lay = tile_layout(params, px, py, rank, flags)
-            if obst.shape != (lay["ny_local"] + 2 * lay["ghost"], lay["nx_local"] + 2 * lay["ghost_x"]):
-                raise ValueError("obstacles_rows must be the rank's window: (ny_local + 2*ghost, nx_local + 2*ghost_x)")
+            if obst.shape != (lay["ny_local"] + 2 * lay["ghost_y"], lay["nx_local"] + 2 * lay["ghost_x"]):
+                raise ValueError("obstacles_rows must be the rank's window: (ny_local + 2*ghost_y, nx_local + 2*ghost_x)")
             self.params, self.free_cells, self.device = params, free_cells, device
             self.y0, self.ny_local, self.x0, self.nx_local = lay["y0"], lay["ny_local"], lay["x0"], lay["nx_local"]
             self.free_cells_inv = np.float32(1.0) / np.float32(free_cells)

@@ -100,7 +100,7 @@ def run_partitions(p, obst, size, steps, kstep):
 
 
 KNOBS = ["LBM_TUNE_MULTI_K", "LBM_TUNE_TILE_MAX", "LBM_TUNE_TILE_GEOM", "LBM_TUNE_MACRO_K", "LBM_TUNE_NARROW_MAX", "LBM_TUNE_MULTI_TILE",
-         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_MACRO_GROUP", "LBM_TUNE_SWEEP", "LBM_TUNE_SWEEP_MODE", "LBM_TUNE_SWEEP_BLOCKS"]
+         "LBM_TUNE_TILE_SINGLE_MAX", "LBM_P2P_SCHEDULE", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_MACRO_GROUP", "LBM_TUNE_TILE_GHOST_ROWS", "LBM_TUNE_SWEEP", "LBM_TUNE_SWEEP_MODE", "LBM_TUNE_SWEEP_BLOCKS"]
 
 
 def main(argv=None) -> int:
@@ -221,6 +221,8 @@ def fuzz(a) -> int:
                     "steps": steps, "dens": dens, "walls": bool(rng.random() < 0.5), "seed": int(rng.integers(1, 1 << 30)),
                     "density": p.density, "accel": p.accel, "omega": p.omega,
                     "env": {k: v for k, v in env.items() if k in ("LBM_TUNE_MACRO_K", "LBM_TUNE_MULTI_TILE", "LBM_TUNE_MACRO_GHOST", "LBM_TUNE_MACRO_GROUP")}}
+            if rng.random() < 0.4:
+                spec["env"]["LBM_TUNE_TILE_GHOST_ROWS"] = "1"      # column blocks (py = 1) that keep ghost rows instead of wrapping in the launch
             child_env = {k: v for k, v in os.environ.items() if k not in KNOBS}
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--tiles-case", json.dumps(spec)], capture_output=True, text=True, timeout=600, env=child_env)
             line = ([l for l in r.stdout.splitlines() if l.startswith("tiles ")] or ["tiles: no verdict"])[-1]

@@ -208,7 +208,8 @@ PY
       short() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], 'us/step %.2f' % (d['ms_per_step']*1e3), d['config']['loop'], d['config'].get('p2p'), (d.get('parity_check') or {}).get('ok'))" "$1"; }
       for pair in 2048x512:16384x64 4096x256:32768x32 8192x128:65536x16; do
         local tl=${pair%%:*} rw=${pair#*:}
-        python bench.py --ring --rank-grid 1x1 --workload $tl --steps 1000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/wide_tile_ring_${tl}.json" && short "$P/wide_tile_ring_${tl}.json" || return 1
+        python bench.py --ring --rank-grid 1x1 --column-block --workload $tl --steps 1000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/wide_tile_ring_${tl}.json" && short "$P/wide_tile_ring_${tl}.json" || return 1
+        python bench.py --ring --rank-grid 1x1 --workload $tl --steps 1000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/wide_tile_ring_${tl}_ghost_rows.json" && short "$P/wide_tile_ring_${tl}_ghost_rows.json" || return 1
         python bench.py --ring --exchange p2p --workload $rw --steps 1000 --warmup 30 --reps 3 --no-cpu-baseline --no-variants --no-secondary > "$P/wide_row_ring_${rw}.json" && short "$P/wide_row_ring_${rw}.json" || return 1
       done ;;
     decks)

@@ -1206,8 +1206,12 @@ def test_p2p_partitions_in_one_process(lbm, nx, ny, size, K, schedule):
 
 
 TILE_CASES = [   # nx ny px py K ghost group runs [walls]
-    "512 256 1 1 4 - - 20,11",            # one rank: its own neighbour in all four directions (and on both diagonals)
-    "512 256 2 1 4 - - 20,11",            # column blocks only
+    "512 256 1 1 4 - - 20,11 yghost",     # one rank: its own neighbour in all four directions (and on both diagonals)
+    "512 256 2 1 4 - - 20,11 yghost",     # column blocks that keep ghost rows (each rank its own south / north neighbour through the row push)
+    "512 256 1 1 4 - - 20,11",            # column blocks proper (py = 1): no ghost rows, the rows wrap inside the launch, only columns travel
+    "512 256 2 1 4 - - 20,11",
+    "520 100 4 1 3 - - 19,7 walls",       # ... K = 3, rows the tile height does not divide
+    "1028 203 3 1 4 7 - 25,3",            # ... uneven column blocks, an odd row count, one launch per exchange
     "512 256 1 2 4 - - 20,11",            # row blocks with ghost columns that wrap onto the rank itself
     "512 256 2 2 4 - - 20,11 walls",
     "768 384 3 2 4 - - 33",
@@ -1222,10 +1226,11 @@ TILE_CASES = [   # nx ny px py K ghost group runs [walls]
     "1028 200 3 1 4 - - 10,11",
     "590 267 2 3 1 16 - 18,19",           # K = 1: eight one-step launches per exchange
     # the edge-stream schedule of a tile rank: the rectangle of tiles inside the rim beside the exchange, the rim behind it
-    "512 256 1 1 4 - - 20,11 sched=edge",
-    "512 256 1 1 4 0 - 20,11 walls sched=edge",          # one launch per exchange
-    "580 300 1 1 3 - - 31 sched=edge",
-    "2048 1100 1 1 4 - - 17,8 sched=edge",
+    "512 256 1 1 4 - - 20,11 sched=edge yghost",
+    "512 256 1 1 4 0 - 20,11 walls sched=edge yghost",   # one launch per exchange
+    "580 300 1 1 3 - - 31 sched=edge yghost",
+    "2048 1100 1 1 4 - - 17,8 sched=edge yghost",
+    "2048 1100 1 1 4 - - 17,8 sched=edge",               # a column block: the rim is two tile columns
     "448 256 4 1 4 - - 13,9",             # blocks narrower than two tiles: 112 owned columns in storage rows of 144
     "512 256 2 2 4 - - 20,11 walls flags=64",     # the other two forms of the sum|u| terms in the tile launch form (LBM_FLAG_FAST_AVVELS / _EXACT_AVVELS)
     "768 384 3 2 4 - - 33 flags=128",

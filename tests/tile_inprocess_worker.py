@@ -1,8 +1,9 @@
 """The ranks of a px x py TILE (2-D) decomposition as contexts of ONE process, one host thread per rank (test helper, run as a
 fresh process by tests/test_gpu_parity.py with GPU_MAX_HW_QUEUES raised, as tests/p2p_inprocess_worker.py).  Every rank keeps ghost
 rows and ghost columns; per exchange the columns travel west / east first, then whole storage rows south / north.
-argv: nx ny px py K ghost group runs(comma separated) [walls] [flags=<lbm_create flags>] [sched=edge|serial]
-(ranks of one process on one device run the serial schedule whatever is asked for; a 1 x 1 grid takes the edge-stream schedule when asked)"""
+argv: nx ny px py K ghost group runs(comma separated) [walls] [flags=<lbm_create flags>] [sched=edge|serial] [yghost]
+(yghost: LBM_TUNE_TILE_GHOST_ROWS=1 — column blocks (py = 1) keep ghost rows and push rows onto themselves instead of wrapping in the launch;
+ranks of one process on one device run the serial schedule whatever is asked for; a 1 x 1 grid takes the edge-stream schedule when asked)"""
 import os
 import sys
 
@@ -19,6 +20,9 @@ def main() -> int:
     runs = [int(v) for v in sys.argv[8].split(",")]
     walls = "walls" in sys.argv[9:]
     flags = next((int(a.split("=")[1]) for a in sys.argv[9:] if a.startswith("flags=")), 0)
+    os.environ.pop("LBM_TUNE_TILE_GHOST_ROWS", None)
+    if "yghost" in sys.argv[9:]:
+        os.environ["LBM_TUNE_TILE_GHOST_ROWS"] = "1"
     sched = next((a.split("=")[1] for a in sys.argv[9:] if a.startswith("sched=")), "")
     os.environ.pop("LBM_P2P_SCHEDULE", None)
     if sched:
@@ -47,6 +51,8 @@ def main() -> int:
     rings = lbm.P2PRing.local_ring(parts)
     d = rings[0].describe()
     assert f"tiles {px} x {py}" in d and ("edge stream" if (sched == "edge" and size == 1) else "serial") in d, d
+    assert ("rows wrap in the launch" in d) == (py == 1 and "yghost" not in sys.argv[9:]), d
+    assert lays[0]["ghost_y"] == (0 if "rows wrap" in d else lays[0]["ghost"])
     out = [lbm.P2PRing.run_all(rings, n) for n in runs]
     for o in out:
         for r in range(1, size):                                # the reduction is bitwise the same on every rank
