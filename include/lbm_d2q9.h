@@ -156,10 +156,11 @@ typedef struct lbm_tile_layout {
 } lbm_tile_layout;
 int lbm_decompose_columns(int nx, int px, int* nx_local, int* displs);
 int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned flags, lbm_tile_layout* out);
-/* Row blocks or tiles for `nranks` ranks, by the measurements of DESIGN.md 6.5: the reference's row blocks unless the thinnest rank would
- * have fewer than 128 rows and a rank holds at least 2^18 cells (row blocks of >= 128 rows beat tiles of the same cells at every size
- * measured; thin AND large ones lose by 1.4 - 1.9 x); then the tile grid whose ranks recompute the smallest share of cells they do not
- * own.  A function of p, nranks and flags only.  *px == 1: row blocks (lbm_create_rank); otherwise lbm_create_tile on *px x *py. */
+/* Row blocks or tiles for `nranks` ranks: the decomposition whose ranks recompute the smallest share of cells they do not own (ghost rows
+ * advanced by the first launches of a group, ghost columns in every launch; thin row blocks charged for their frequent exchanges, tiles
+ * with ghost rows for their second exchange kernel) — a rule that orders every pair measured: the reference's row blocks
+ * for the square decks, wide column blocks (px x 1) where row blocks would be 128 rows or thinner.  A function of p, nranks and flags
+ * only.  *px == 1: row blocks (lbm_create_rank); otherwise lbm_create_tile on *px x *py. */
 int lbm_choose_rank_grid(const lbm_params* p, int nranks, unsigned flags, int* px, int* py);
 /* obstacle_window: (ny_local + 2*ghost_y) rows of (nx_local + 2*ghost_x) ints — global rows y0-ghost_y .., global columns x0-ghost_x ..,
  * both wrapping periodically.  lbm_get_cells / lbm_set_cells / lbm_get_observables of such a context move its ny_local x nx_local

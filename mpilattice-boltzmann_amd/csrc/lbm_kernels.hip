@@ -1016,39 +1016,39 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
   return 0;
 }
 
-// Row blocks or tiles, and which tiles, for `nranks` ranks.  Measured on 1-rank rings (profiles/r04/wide_*.json, tile_*.json,
-// auto_*.json), a rank's share as a row block against a block of a tiling of the same cells:
-//   row blocks of >= 128 rows win at every size (8192 x 1024 43.9 against 45.5 us/step, 2048 x 256 5.5 against 6.2, 1024 x 128 3.3 against 4.1):
-//     a tile rank pays a second exchange kernel and recomputes its ghost columns in every launch;
-//   thinner row blocks lose once they are LARGE: 16384 x 64 rows 13.2 against 9.7 as 2048 x 512, 32768 x 32 18.3 against 10.6, 65536 x 16
-//     (one-step loop) 21.9 against 11.8 — their launches spend a large share on ghost rows, or they exchange every 4 steps or every step;
-//   thin and SMALL ones do not: 2048 x 64 rows 4.15 against 4.18 as 1024 x 128, 1024 x 64 rows 3.25 against 3.51 as 512 x 128.
-// Hence: row blocks unless the thinnest rank has fewer than 128 rows AND a rank holds at least 2^18 cells; then the tile grid whose ranks
-// recompute the smallest fraction of cells they do not own — a rank of R rows and C columns with g ghost rows / columns advances, averaged
-// over a group of launches, about 3/8 g ghost rows per side and all 2 g ghost columns: 0.75 g / R + 2 g / C — blocks thinner than 128 / 64
-// rows charged as the row blocks' were.  A function of p, nranks and flags only.  *px == 1 means ROW BLOCKS (lbm_create_rank: no ghost
-// columns), anything else lbm_create_tile on *px x *py.
+// Row blocks or tiles, and which tiles, for `nranks` ranks: the decomposition whose ranks recompute the smallest share of cells they do not own.
+// A rank of R rows and C columns that keeps g ghost rows / columns advances, averaged over a group of launches, about 3/8 g ghost rows per
+// side (the first launch of a group g - k of them, the last none) and — tiles — all 2 g ghost columns in every launch:
+//     row blocks     0.75 g / R              + 0.1 below 128 rows (an exchange every 8 steps), + 0.2 below 64 (every 4), + 1 below 32 (one-step loop)
+//     column blocks  2 g / C                 (px x 1 tilings: no ghost rows, one exchange kernel)
+//     other tiles    0.75 g / R + 2 g / C + 0.05 (the second exchange kernel), thin blocks charged as thin row blocks are
+// The rule orders all 21 pairs measured on 1-rank rings as they came out (profiles/r04/{wide,tile,auto,column}_*.json), us/step
+// rows / tiles of the same cells: 8192 x 1024 43.8 / 46.0 as 1024 x 8192 column blocks and 45.5 as 2048 x 4096; 1024 x 128 3.28 / 4.05 as 128 x 1024,
+// 4.13 as 256 x 512; 1024 x 256 3.99 / 4.93; 2048 x 256 5.5 / 6.2; 1024 x 64 3.25 / 3.51 as 512 x 128 (rows: a second exchange kernel and ghost
+// columns cost more than the ghost rows of blocks this tall, or than a small block's frequent exchanges) — and 2048 x 128 4.36 / 4.01 as 512 x 512
+// column blocks, 4096 x 128 6.15 / 5.37, 2048 x 64 4.12 / 3.31, 4096 x 64 5.38 / 4.03, 8192 x 64 7.45 / 5.64, 16384 x 64 13.2 / 8.7, 32768 x 32 18.3 / 9.4,
+// 65536 x 16 21.8 / 9.5 (tiles: wide column blocks beat row blocks of up to 128 rows).  Every BASELINE.json config comes out as row blocks.
+// A function of p, nranks and flags only.  *px == 1 means ROW BLOCKS (lbm_create_rank: no ghost columns), anything else lbm_create_tile on *px x *py.
 int lbm_choose_rank_grid(const lbm_params* p, int nranks, unsigned flags, int* px, int* py)
 {
   if (!p || !px || !py || nranks < 1) { lbm_internal::set_error("lbm_choose_rank_grid: bad argument"); return 1; }
   *px = 1; *py = nranks;
   lbm_layout rows;
   if (lbm_rank_layout(p, nranks, nranks - 1, flags, &rows)) return 1;
+  if (nranks == 1) return 0;
   std::vector<int> nyl(nranks), dis(nranks);
   if (lbm_decompose(p->ny, nranks, nyl.data(), dis.data())) return 1;
-  const int rmin = *std::min_element(nyl.begin(), nyl.end()), rmax = *std::max_element(nyl.begin(), nyl.end());
-  if (nranks == 1 || rmin >= 128 || static_cast<size_t>(p->nx) * rmax < (size_t(1) << 18)) return 0;
-  double best = 1e30;
+  const int rmin = *std::min_element(nyl.begin(), nyl.end());
+  auto thin = [](int r) { return (r < 128 ? 0.1 : 0.0) + (r < 64 ? 0.2 : 0.0); };
+  double best = rows.macro_k > 0 ? 0.75 * rows.ghost / rmin + thin(rmin) : 1.0 + thin(rmin);
   for (int qx = 2; qx <= nranks; ++qx) {
     if (nranks % qx != 0) continue;
     lbm_tile_layout t;
     if (lbm_tile_layout_of(p, qx, nranks / qx, nranks - 1, flags, &t)) continue;      // a rank would fall out of K-step mode: not a candidate
     // (the last rank holds the smallest column block and, by the reference's rule, not the largest row block)
-    const double cost = 0.75 * t.ghost / t.ny_local + 2.0 * t.ghost_x / t.nx_local + (t.ny_local < 128 ? 0.1 : 0.0) + (t.ny_local < 64 ? 0.2 : 0.0);
+    const double cost = t.ghost_y > 0 ? 0.75 * t.ghost_y / t.ny_local + 2.0 * t.ghost_x / t.nx_local + 0.05 + thin(t.ny_local) : 2.0 * t.ghost_x / t.nx_local;
     if (cost < best) { best = cost; *px = qx; *py = nranks / qx; }
   }
-  // (a tile grid no better than the thin row blocks themselves — every candidate thinner than 128 rows as well — is not worth the second exchange)
-  if (*px != 1 && best >= 0.75 * std::max(rows.ghost, 1) / rmin + (rmin < 64 ? 0.3 : 0.1) + (rmin < 32 ? 1.0 : 0.0)) { *px = 1; *py = nranks; }
   (void)lbm_last_error();
   return 0;
 }

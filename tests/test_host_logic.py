@@ -698,18 +698,24 @@ def test_tile_layout_is_one_decision_for_all_ranks(lbm, monkeypatch):
 
 
 def test_rank_grid_choice_follows_the_measurements(lbm):
-    """lbm_choose_rank_grid: the reference's row blocks (d2q9-bgk.c:834-862) wherever they measured faster — every deck whose ranks keep >= 128
-    rows, and thin but small ones — and tiles for the grids much wider than tall that SURVEY.md section 8(f) row 3 names (the pairs
-    behind each line); the same answer on every rank (a function of p, nranks, flags)."""
+    """lbm_choose_rank_grid: the reference's row blocks (d2q9-bgk.c:834-862) wherever they measured faster — every BASELINE.json config, and small
+    decks on many ranks — and tiles where they did: wide column blocks in place of row blocks of 128 rows or fewer, the grids much wider than
+    tall that SURVEY.md section 8(f) row 3 names (DESIGN.md 6.5 lists the measured pair behind each line); the same answer on every rank."""
     P = lambda nx, ny: lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
-    rows = [(8192, 8192, 8), (8192, 8192, 2), (1024, 1024, 8), (1024, 1024, 16), (2048, 512, 8), (2048, 512, 4), (128, 128, 4), (8192, 8192, 1), (16384, 1024, 8)]
-    for nx, ny, n in rows:
+    for nx, ny, n in [(8192, 8192, 8), (8192, 8192, 4), (8192, 8192, 2), (8192, 8192, 1),      # 8192 x 1024 rows 43.8 us/step against 46.0 as 1024 x 8192 column blocks
+                      (1024, 1024, 8), (1024, 1024, 4), (1024, 1024, 2),                       # 1024 x 128 rows 3.28 against 4.05 as 128 x 1024; 1024 x 256 3.99 / 4.93
+                      (1024, 1024, 16),                                                        # 1024 x 64 rows 3.25 against 3.51 as 512 x 128 tiles
+                      (128, 128, 4), (256, 256, 2), (128, 256, 2)]:                            # the small shipped decks: no tiling is eligible
         assert lbm.choose_rank_grid(P(nx, ny), n) is None, (nx, ny, n)
-    assert lbm.choose_rank_grid(P(16384, 512), 8) == (8, 1)          # 64-row blocks of 1 M cells: 13.2 us/step against 9.7 as 2048 x 512
-    assert lbm.choose_rank_grid(P(32768, 256), 8) == (8, 1)          # 32-row blocks: 18.3 against 10.6
-    assert lbm.choose_rank_grid(P(65536, 128), 8) == (8, 1)          # 16-row blocks (one-step loop): 21.9 against 11.8
-    px, py = lbm.choose_rank_grid(P(16384, 512), 16)
-    assert px * py == 16 and px > 1 and lbm.tile_layout(P(16384, 512), px, py, 0)["ny_local"] >= 128
+    assert lbm.choose_rank_grid(P(16384, 512), 8) == (8, 1)          # 64-row blocks 13.2 us/step against 8.7 as 2048 x 512 column blocks
+    assert lbm.choose_rank_grid(P(32768, 256), 8) == (8, 1)          # 32-row blocks: 18.3 against 9.4
+    assert lbm.choose_rank_grid(P(65536, 128), 8) == (8, 1)          # 16-row blocks (one-step loop): 21.8 against 9.5
+    assert lbm.choose_rank_grid(P(2048, 512), 4) == (4, 1)           # 2048 x 128 rows 4.36 against 4.01 as 512 x 512
+    assert lbm.choose_rank_grid(P(2048, 512), 8) == (8, 1)           # 2048 x 64 rows 4.12 against 3.31 as 256 x 512
+    assert lbm.choose_rank_grid(P(4096, 512), 4) == (4, 1)           # 4096 x 128 rows 6.15 against 5.37 as 1024 x 512
+    assert lbm.choose_rank_grid(P(8192, 256), 4) == (4, 1)           # 8192 x 64 rows 7.45 against 5.64 as 2048 x 256
+    px, py = lbm.choose_rank_grid(P(4096, 4096), 64)                 # 64-row blocks; 64-column blocks are not eligible: tiles with ghost rows
+    assert px * py == 64 and px > 1 and py > 1 and lbm.tile_layout(P(4096, 4096), px, py, 0)["ny_local"] >= 128
     assert lbm.choose_rank_grid(P(16384, 512), 8, lbm._capi.FLAG_ONE_STEP) is None       # no K-step mode, no tiles
     with pytest.raises(lbm.LbmError):
         lbm.choose_rank_grid(P(16384, 512), 0)
