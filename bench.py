@@ -1127,14 +1127,15 @@ def main() -> int:
                 bank(out)
 
     # ---- BASELINE.json config 4: the shipped 1024x1024 deck on the same ranks ------------------------------------------
-    def secondary_1024():
-        digests = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))["1024x1024"]
+    def deck_on_ranks(name: str, modes, steps_override: int = 0):
+        digests = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))[name]
         p4 = lbm.read_params(os.path.join(DECKS, digests["params"]))
         o4, _ = lbm.read_obstacles(os.path.join(DECKS, digests["obstacles"]), p4.nx, p4.ny)
-        n4 = args.secondary_steps if args.secondary_steps > 0 else p4.max_iters
-        res = {"deck": "input_1024x1024.params + obstacles_1024x1024.dat (tests/golden/decks: the reference's own files)", "steps": n4,
-               "reference_published_s": 5.90364, "reference_published_note": "d2q9-bgk_best.out:8-12, 64 MPI ranks on 4 x 16 Xeon E5-2670 cores, 20 000 steps"}
-        for mode in ("p2p", "rccl", "p2p_tiles"):
+        n4 = steps_override if steps_override > 0 else p4.max_iters
+        res = {"deck": f"input_{name}.params + obstacles_{name}.dat (tests/golden/decks: the reference's own files)", "steps": n4}
+        if name == "1024x1024":
+            res.update(reference_published_s=5.90364, reference_published_note="d2q9-bgk_best.out:8-12, 64 MPI ranks on 4 x 16 Xeon E5-2670 cores, 20 000 steps")
+        for mode in modes:
             if mode == "rccl" and shared_gpu:
                 res[mode] = {"error": "not usable: ranks share a GPU (RCCL refuses duplicate devices)"}
                 continue
@@ -1162,10 +1163,18 @@ def main() -> int:
         return res
 
     if partitioned and not args.no_secondary:
-        sec = optional_part("secondary: input_1024x1024", 40.0, secondary_1024)
+        sec = optional_part("secondary: input_1024x1024", 40.0, lambda: deck_on_ranks("1024x1024", ("p2p", "rccl", "p2p_tiles"), args.secondary_steps))
         if rank == 0:
             out["secondary"] = {"input_1024x1024": sec}
             bank(out)
+        # the three small shipped decks on the same ranks, whole runs (north_star: "MLUPS on the provided grids ... at 1, 2, 4 and 8 GPUs"): launch-
+        # bound on one GPU, thinner than K-step mode allows from 4 or 8 ranks on (the one-step loop) — numbers for the record, each checked
+        if world > 1 and not args.ring:
+            for name in ("256x256", "128x256", "128x128"):
+                small = optional_part(f"secondary: input_{name}", 30.0, lambda name=name: deck_on_ranks(name, ("p2p",)))
+                if rank == 0:
+                    out["secondary"][f"input_{name}"] = small
+                    bank(out)
 
     if rank == 0:
         if world == 1 and not args.ring and not args.no_cpu_baseline:

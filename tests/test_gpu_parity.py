@@ -1383,6 +1383,9 @@ def test_bench_self_launch_two_ranks_on_one_gpu(lbm):
     sec = out["secondary"]["input_1024x1024"]
     assert sec["steps"] == 3000 and sec["p2p"]["parity_ok"] is True and sec["p2p"]["value"] > 0 and "ranks share a GPU" in sec["rccl"]["error"]
     assert sec["p2p_tiles"]["parity_ok"] is True and "tiles 2 x 1" in sec["p2p_tiles"]["p2p"]
+    for name in ("256x256", "128x256", "128x128"):                  # the small shipped decks on the same ranks, whole runs
+        small = out["secondary"][f"input_{name}"]["p2p"]
+        assert small["parity_ok"] is True and small["reynolds_line_equals_reference"] is True and small["value"] > 0
 
 
 @pytest.mark.parametrize("gpus,name", [(2, "256x256_t1000"), (3, "1024x1024_t200"), (4, "128x256_t2000"), (4, "rand_64x48"), (3, "tall_8x256")])
