@@ -348,6 +348,26 @@ def test_full_size_8192_properties_and_short_parity(lbm, oracle):
         else:
             assert ring.partition.checksum() == digest
         ring.close()
+    # ... and as one rank of the tile (2-D) decomposition at full size: a column block (no ghost rows: the launches wrap in y, only columns
+    # travel) and a block of any tiling (ghost rows and columns; rows pushed onto the rank itself, corners in two hops), under both schedules
+    for ghost_rows, schedule in (("", ""), ("1", "serial"), ("1", "edge")):           # (ranks of >= 2^25 cells take the edge-stream schedule by default)
+        os.environ.pop("LBM_TUNE_TILE_GHOST_ROWS", None)
+        os.environ.pop("LBM_P2P_SCHEDULE", None)
+        if ghost_rows:
+            os.environ["LBM_TUNE_TILE_GHOST_ROWS"] = ghost_rows
+        if schedule:
+            os.environ["LBM_P2P_SCHEDULE"] = schedule
+        try:
+            tile = lbm.Simulation(p, obst, exchange="p2p", strict=True, rank_grid=(1, 1))
+            what = tile.describe()["p2p"]
+            assert ("rows wrap in the launch" in what) == (not ghost_rows) and ("edge stream" in what) == (schedule != "serial"), what
+            av_tile = np.concatenate([tile.run(31), tile.run(19)])
+            assert np.max(np.abs(av_tile - ref_exact) / ref_exact) < AV_EXACT_RTOL
+            assert tile.partition.checksum() == digest, what
+            tile.close()
+        finally:
+            os.environ.pop("LBM_TUNE_TILE_GHOST_ROWS", None)
+            os.environ.pop("LBM_P2P_SCHEDULE", None)
 
 
 def test_mid_size_longer_run(lbm, oracle):
