@@ -87,7 +87,8 @@ def parse_args(argv=None):
                          "and the sustained 3 x 2000-step line; partitioned runs: the shipped 1024x1024 deck on the same ranks (config 4)")
     ap.add_argument("--rank-grid", default="",
                     help="PXxPY: headline over the tile (2-D) decomposition on PX x PY = N ranks instead of the reference's row blocks (peer-to-peer "
-                         "loop only; with --ring: 1x1, a rank that is its own neighbour in every direction)")
+                         "loop only; with --ring: 1x1, a rank that is its own neighbour in every direction); auto: lbm_choose_rank_grid decides "
+                         "(row blocks for the square decks, column blocks for grids much wider than tall)")
     ap.add_argument("--column-block", action="store_true",
                     help="with --ring --rank-grid 1x1: the ring stands for a block of a PX x 1 tiling (a column block: no ghost rows, its rows wrap inside "
                          "the launch, an exchange is the column push alone) instead of a block of any tiling (ghost rows, row push onto itself)")
@@ -619,7 +620,9 @@ def main() -> int:
     flags = lbm._capi.FLAG_FORCE_HALO if args.ring else 0
     partitioned = world > 1 or args.ring
     head_grid = None
-    if args.rank_grid:
+    if args.rank_grid == "auto":                      # lbm_choose_rank_grid: row blocks (None) or the tile grid with the least redundant work
+        head_grid = lbm.choose_rank_grid(params, world, flags) if partitioned else None
+    elif args.rank_grid:
         try:
             head_grid = tuple(int(v) for v in args.rank_grid.lower().split("x"))
             assert len(head_grid) == 2 and head_grid[0] * head_grid[1] == world and partitioned
