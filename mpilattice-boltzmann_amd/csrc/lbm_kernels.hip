@@ -1020,9 +1020,10 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
 // A rank of R rows and C columns that keeps g ghost rows / columns advances, averaged over a group of launches, about 3/8 g ghost rows per
 // side (the first launch of a group g - k of them, the last none) and — tiles — all 2 g ghost columns in every launch:
 //     row blocks     0.75 g / R              + 0.1 below 128 rows (an exchange every 8 steps), + 0.2 below 64 (every 4), + 1 below 32 (one-step loop)
-//     column blocks  2 g / C                 (px x 1 tilings: no ghost rows, one exchange kernel)
+//     column blocks  2 g / C + 0.02          (px x 1 tilings: no ghost rows, one exchange kernel; the margin: 128-row blocks against 320 / 384 /
+//                                            448 / 512-column blocks came out 4.58 / 5.06, 5.39 / 5.87, 5.80 / 5.61, 4.36 / 4.01 us/step)
 //     other tiles    0.75 g / R + 2 g / C + 0.05 (the second exchange kernel), thin blocks charged as thin row blocks are
-// The rule orders all 21 pairs measured on 1-rank rings as they came out (profiles/r04/{wide,tile,auto,column}_*.json), us/step
+// The rule orders the 25 pairs measured on 1-rank rings as they came out (profiles/r04/{wide,tile,auto,column}_*.json), us/step
 // rows / tiles of the same cells: 8192 x 1024 43.8 / 46.0 as 1024 x 8192 column blocks and 45.5 as 2048 x 4096; 1024 x 128 3.28 / 4.05 as 128 x 1024,
 // 4.13 as 256 x 512; 1024 x 256 3.99 / 4.93; 2048 x 256 5.5 / 6.2; 1024 x 64 3.25 / 3.51 as 512 x 128 (rows: a second exchange kernel and ghost
 // columns cost more than the ghost rows of blocks this tall, or than a small block's frequent exchanges) — and 2048 x 128 4.36 / 4.01 as 512 x 512
@@ -1046,7 +1047,7 @@ int lbm_choose_rank_grid(const lbm_params* p, int nranks, unsigned flags, int* p
     lbm_tile_layout t;
     if (lbm_tile_layout_of(p, qx, nranks / qx, nranks - 1, flags, &t)) continue;      // a rank would fall out of K-step mode: not a candidate
     // (the last rank holds the smallest column block and, by the reference's rule, not the largest row block)
-    const double cost = t.ghost_y > 0 ? 0.75 * t.ghost_y / t.ny_local + 2.0 * t.ghost_x / t.nx_local + 0.05 + thin(t.ny_local) : 2.0 * t.ghost_x / t.nx_local;
+    const double cost = t.ghost_y > 0 ? 0.75 * t.ghost_y / t.ny_local + 2.0 * t.ghost_x / t.nx_local + 0.05 + thin(t.ny_local) : 2.0 * t.ghost_x / t.nx_local + 0.02;
     if (cost < best) { best = cost; *px = qx; *py = nranks / qx; }
   }
   (void)lbm_last_error();
