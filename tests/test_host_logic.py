@@ -57,6 +57,15 @@ int main(void)
   if (lbm_decompose(10, 3, ny_local, displs)) return 3;
   if (lbm_rank_layout(&p, 6, 5, LBM_FLAG_DEFAULT, &lay)) return 4;
   printf("%d %d %d | %d %d %d\\n", ny_local[0], ny_local[1], ny_local[2], lay.y0, lay.ny_local, lay.macro_k);
+  {                                     /* the tile (2-D) decomposition's host half, as INTEGRATION.md section 3c uses it */
+    lbm_params wide = {16384, 512, 10, 10, 0.1f, 0.005f, 1.85f};
+    lbm_tile_layout t;
+    int px = 0, py = 0, nxl[8], xd[8];
+    if (lbm_choose_rank_grid(&wide, 8, LBM_FLAG_DEFAULT, &px, &py)) return 5;
+    if (lbm_tile_layout_of(&wide, px, py, 7, LBM_FLAG_DEFAULT, &t)) return 6;
+    if (lbm_decompose_columns(wide.nx, px, nxl, xd)) return 7;
+    printf("%d x %d | %d %d %d %d | %d %d %d\\n", px, py, t.x0, t.nx_local, t.y0, t.ny_local, t.ghost, t.ghost_x, t.ghost_y);
+  }
   return 0;
 }
 ''')
@@ -66,7 +75,7 @@ int main(void)
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 0 and r.stdout == "4 3 3 | 159 31 0\n", (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout == "4 3 3 | 159 31 0\n8 x 1 | 14336 2048 0 512 | 16 16 0\n", (r.returncode, r.stdout, r.stderr)
 
 
 def test_rccl_library_exports_every_declared_symbol(lbm):
@@ -719,6 +728,36 @@ def test_rank_grid_choice_follows_the_measurements(lbm):
     assert lbm.choose_rank_grid(P(16384, 512), 8, lbm._capi.FLAG_ONE_STEP) is None       # no K-step mode, no tiles
     with pytest.raises(lbm.LbmError):
         lbm.choose_rank_grid(P(16384, 512), 0)
+
+
+def test_rank_grid_choice_is_always_a_runnable_decomposition(lbm):
+    """Property over random grids and rank counts: whatever lbm_choose_rank_grid answers can be created — the row decomposition always can
+    (lbm_rank_layout), a tile grid is px x py = nranks with every rank's layout defined, the blocks tiling the grid exactly and all ranks
+    agreeing on K, the ghost depths and the launches per exchange; the answer does not depend on which rank asks (no rank argument at all)."""
+    rng = np.random.default_rng(11)
+    seen_tiles = 0
+    for _ in range(300):
+        nx = 2 * int(rng.integers(8, 20000)) if rng.random() < 0.8 else int(rng.integers(1, 5000))
+        ny = int(rng.integers(3, 6000))
+        n = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 32, 64]))
+        if ny < n:
+            continue
+        p = lbm.Params(nx, ny, 10, 10, 0.1, 0.005, 1.85)
+        grid = lbm.choose_rank_grid(p, n)
+        assert grid == lbm.choose_rank_grid(p, n)
+        if grid is None:
+            lays = [lbm.rank_layout(p, n, r) for r in range(n)]
+            assert sum(l["ny_local"] for l in lays) == ny
+            continue
+        seen_tiles += 1
+        px, py = grid
+        assert px > 1 and px * py == n
+        lays = [lbm.tile_layout(p, px, py, r) for r in range(n)]
+        assert sum(l["nx_local"] * l["ny_local"] for l in lays) == nx * ny
+        assert len({(l["macro_k"], l["ghost"], l["ghost_x"], l["ghost_y"], l["group"]) for l in lays}) == 1 and lays[0]["macro_k"] > 0
+        assert all(l["nx_local"] % 2 == 0 and l["nx_local"] >= l["ghost_x"] for l in lays)
+        assert lays[0]["ghost_y"] == (0 if py == 1 else lays[0]["ghost"])
+    assert seen_tiles > 20
 
 
 def test_tile_obstacle_window_wraps_in_both_directions(lbm):
