@@ -996,7 +996,8 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
   out->y0 = ydis[out->ry]; out->ny_local = nyl[out->ry];
   const int k = macro_k_for(static_cast<size_t>(chi) * rhi);
   const int ghost = macro_ghost_for(k, chi, rlo, rhi);
-  const int ghost_x = (ghost + 1) & ~1;
+  int ghost_x = (ghost + 1) & ~1;
+  ghost_x = std::min(std::max(tune_env("LBM_TUNE_TILE_GHOST_X", ghost_x) & ~1, ghost_x), kMaxGhost);
   // every rank's storage rows (owned + ghost columns) must be ones the K-step kernels take, and its own columns at least the ghost
   // columns its neighbours need from it
   lbm_params narrow = *p, wide = *p;

@@ -13,7 +13,7 @@
 #   bench[:<bench.py args>]       bench.py (default: the driver's --steps 20 --warmup 5), the line in bench.json
 #   prof[:<bench.py args>]        rocprofv3 --kernel-trace --stats of bench.py, summary in prof/
 #   pmc:<counters>:<bench args>   one rocprofv3 --pmc pass of bench.py (its own run, no trace flags)
-#   pmcsum:<counters>[:<tag>]     the same, then the mean per launch of every counter for lbm_multi_kernel<4 (appended to pmcsum.txt)
+#   pmcsum:<counters>[:<tag>[:<bench args>]]   the same, then the mean per launch of every counter for lbm_multi_kernel<4 (appended to pmcsum.txt)
 #   uselib:<variant>              ON THE BOX: lib/variants/<variant>.so takes the place of lib/liblbm_d2q9.so for the steps that follow
 #   round[:<workload>]            the record behind bench.py's `roofline` for profiles/<tag>/: rocprofv3 --kernel-trace --stats of the default bench.py,
 #                                 FETCH_SIZE / WRITE_SIZE / two SQ --pmc passes at the driver's 20 steps (each its own run), scripts/make_roofline.py,
@@ -101,9 +101,9 @@ PY
       timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py ${rest:---steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-phases --no-power} > "$d.json" 2> "$d.err"
       local rc=$?; tail -3 "$d.err"; return $rc ;;
     pmcsum)
-      local ctr=${arg%%:*} lab=""; [ "$ctr" != "$arg" ] && lab=${arg#*:}
+      local ctr lab rest; IFS=: read -r ctr lab rest <<< "$arg"
       local d="$OUT/pmcsum_${lab:-x}"; rm -rf "$d"
-      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py --steps 20 --warmup 5 --reps 2 --no-cpu-baseline --no-variants --no-secondary --no-phases --no-power > "$d.json" 2> "$d.err" || { tail -5 "$d.err"; return 1; }
+      timeout -k 10 500 rocprofv3 --pmc $ctr -d "$d" -o pmc --output-format csv -- python3 bench.py ${rest:---steps 20 --warmup 5 --reps 2} --no-cpu-baseline --no-variants --no-secondary --no-phases --no-power > "$d.json" 2> "$d.err" || { tail -5 "$d.err"; return 1; }
       python - "$d" "$lab" <<'PY' | tee -a "$OUT/pmcsum.txt"
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
