@@ -139,6 +139,8 @@ struct MultiArgs {
   // launch that reads no exchanged row or column is one rectangle (tile rows x tile columns inside the rim), the rim the four around it.
   int nrect;
   struct Rect { int ty0, tx0, ntx, count; } rect[4];       // tile rows from ty0, tile columns [tx0, tx0 + ntx); count = rows x ntx blocks
+  int nblocks;                     // kPartTile: tiles of this launch; the grid is padded to a multiple of 8 blocks so that the XCD-contiguous order
+                                   // (xcd_remap) applies to any tile count — a tile rank's storage rows are never a multiple of 8 tiles wide
 };
 
 // A pair (x, x+1), x even, of population k into row `row` (a dword index) of an LDS frame of row stride W: interleaved
@@ -228,6 +230,9 @@ __global__ void __launch_bounds__((MultiGeom<K, GEOM>::LANES), (MultiGeom<K, GEO
     // the launch so that tiles which overlap (x and y neighbours) meet in the same L2
     const int nb = gridDim.x - 1, per = nb >> 3;
     b = (b & 7) * per + (b >> 3);
+  }
+  if constexpr (PART == kPartTile) {
+    if (b >= a.nblocks) return;                      // padding of the grid (block-uniform)
   }
   int tile_of_block = b < a.tile_count ? a.tile_begin + b : a.tile_begin2 + (b - a.tile_count);
   if constexpr (PART == kPartTile) {

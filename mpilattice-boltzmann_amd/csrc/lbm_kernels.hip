@@ -390,6 +390,11 @@ void launch_multi(lbm_ctx* c, int ksteps, int ext, bool accel_last, int t0, int 
   }
   // measured on 8192x8192, K=2: 515 us/step with the XCD-contiguous tile order, 549 without
   a.xcd_remap = (tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks % 8 == 0 && blocks >= 64) ? 1 : 0;
+  a.nblocks = blocks;
+  if (c->ghost_x > 0 && tune_env("LBM_TUNE_MULTI_REMAP", 1) && blocks >= 64 && blocks % 8 != 0 && tune_env("LBM_TUNE_TILE_PAD_GRID", 1)) {
+    blocks = (blocks + 7) / 8 * 8;                              // tile ranks: pad the grid (the form drops the extra blocks) and keep the XCD-contiguous order
+    a.xcd_remap = 1;
+  }
   // the instantiation that does exactly `ksteps` steps: the tail of a run whose step count multi_K does not
   // divide is a launch of a smaller frame, not a run-time loop bound (which cost scratch and ~10 % speed)
   // the instantiation (kernels/multi.h PART): ghost rows computed too -> the counted test; ready words to say -> the fold block carries them
