@@ -1425,7 +1425,8 @@ def test_cli_drives_several_ranks_from_one_process(lbm, digests, tmp_path, gpus,
     assert np.allclose(av[np.asarray(digests[name]["av_sample_steps"])], digests[name]["av_sample_values"], rtol=5e-4)
 
 
-@pytest.mark.parametrize("gpus,grid,name", [(4, "2x2", "1024x1024_t200"), (2, "2x1", "256x256_t1000"), (2, "1x2", "256x256_t1000"), (8, "4x2", "1024x1024_t200")])
+@pytest.mark.parametrize("gpus,grid,name", [(4, "2x2", "1024x1024_t200"), (2, "2x1", "256x256_t1000"), (2, "1x2", "256x256_t1000"), (8, "4x2", "1024x1024_t200"),
+                                            (8, "8x1", "1024x1024_t200")])     # eight column blocks of 128 columns: no ghost rows, the launches wrap in y
 def test_cli_drives_a_tile_decomposition_from_one_process(lbm, digests, tmp_path, gpus, grid, name):
     """LBM_GPUS=N LBM_RANK_GRID=PXxPY: the same single-process host over the tile (2-D) decomposition — the shipped decks end in the
     reference binary's final_state.dat byte for byte, whichever way the grid is cut (4 x 2: BASELINE.json config 4's eight ranks)."""
