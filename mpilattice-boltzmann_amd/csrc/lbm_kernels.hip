@@ -865,6 +865,14 @@ static int create_impl(lbm_ctx** out, const lbm_params* p, int free_cells, const
     for (int i = 0; i < 2; ++i) HIP_TRY_C(hipMalloc(&c->macro_pack[i], sizeof(float) * pack_floats));
     c->tile_kernel = false;
     c->multi_geom = pick_geom(c->ncells);
+    if (tile && c->ghost_rows == 0 && c->multi_geom == kGeomTall && tune_env("LBM_TUNE_MULTI_GEOM", -1) < 0) {
+      // A column block's launches all cover exactly its ny rows: where 23-row tiles fit them badly the last tile row is mostly waste — 256 rows: 12
+      // tile rows cover 276 (7.8 % over) against 260 on 13-row tiles; 128 rows: 138 against 130 — and the standard geometry wins by 10 % (us/step
+      // tall / standard: 4096 x 256 8.96 / 8.11, 8192 x 128 9.40 / 8.37; 512 and 1024 rows fit: 2048 x 512 7.82 / 8.25, 1024 x 1024 8.20 / 8.60, 2048 x 1024
+      // 13.8 / 14.1; profiles/r04/ab_column_block_geometry.txt).  Row blocks and whole grids compute different row counts from launch to launch (no rule).
+      auto over = [&](int ty) { return static_cast<double>((ny_local + ty - 1) / ty * ty) / ny_local; };
+      if (over(kMTY4Tall) - over(kMTY4) > 0.03) c->multi_geom = kGeomStd;
+    }
     c->multi_tx = geom_tx(c->multi_geom);
     HIP_TRY_C(raise_multi_lds_limits_for(c->multi_geom));
     c->multi_tiles_x = (p->nx + c->multi_tx - 1) / c->multi_tx;
