@@ -28,7 +28,8 @@
  * (their own flags and "ready" words), awaited, and then the row push above over whole storage rows — the ghost columns that have just
  * arrived included, which brings the corner blocks along.  The part of a group's first launch that runs beside the exchange is the
  * rectangle of tiles inside the rim of tile rows and tile columns that read exchanged cells (ranks of >= 2^25 cells; smaller ones run
- * everything on the compute stream).
+ * everything on the compute stream).  Column blocks (py = 1: every rank owns all rows; lbm_tile_layout.ghost_y == 0) keep no ghost rows: their launches
+ * wrap in y like a whole grid's and an exchange is the column push alone.
  *
  * Set-up is a two-phase handshake the caller carries by any means (this repo: torch.distributed
  * all_gather of LBM_P2P_HANDLE_BYTES per rank; the C CLI: an array in its own address space):
