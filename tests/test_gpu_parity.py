@@ -1155,7 +1155,9 @@ MULTI_GPU_CASES = {
         dict(nx=256, ny=400, K=0, schedule="", runs=[37, 20]), dict(nx=256, ny=400, K=0, schedule="edge", runs=[37, 20], exchange="rccl"),
         dict(nx=1024, ny=300, K=4, schedule="edge", runs=[21, 20], ghost="12", scatter=True),
         # tile (2-D) decomposition over a real link: two column blocks (columns west / east across the link, rows onto the rank itself)
-        dict(nx=2048, ny=1100, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True, p=0.005), dict(nx=484, ny=78, K=1, schedule="", runs=[9, 10], grid=[2, 1], ghost="4", group="2")],
+        dict(nx=2048, ny=1100, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True, p=0.005), dict(nx=484, ny=78, K=1, schedule="", runs=[9, 10], grid=[2, 1], ghost="4", group="2"),
+        # ... and two ROW blocks of tile ranks (ghost rows and ghost columns; rows and corners across the link, columns onto the rank itself), both schedules
+        dict(nx=1024, ny=512, K=0, schedule="", runs=[20, 11], grid=[1, 2], scatter=True), dict(nx=1024, ny=512, K=0, schedule="edge", runs=[9, 12], grid=[1, 2])],
     3: [dict(nx=256, ny=200, K=3, schedule="edge", runs=[20, 11]), dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
         dict(nx=772, ny=96, K=0, schedule="", runs=[13, 8], grid=[3, 1], scatter=True),
         dict(nx=256, ny=200, K=3, schedule="", runs=[20, 11], exchange="rccl", scatter=True),
