@@ -1099,7 +1099,8 @@ P2P_CASES = {
         dict(nx=130, ny=100, K=4, schedule="edge", runs=[20, 11], ghost="0"), dict(nx=192, ny=99, K=4, schedule="edge", runs=[37, 20], ghost="16"),
         # tile (2-D) decomposition: two column blocks (each rank is its own south / north neighbour and the other's west AND east one)
         dict(nx=512, ny=128, K=0, schedule="", runs=[20, 11], grid=[2, 1], walls=True),
-        dict(nx=1024, ny=256, K=0, schedule="edge", runs=[20, 11], grid=[2, 1]), dict(nx=1024, ny=256, K=4, schedule="edge", runs=[9, 8], grid=[1, 2], ghost="0")],
+        dict(nx=1024, ny=256, K=0, schedule="edge", runs=[20, 11], grid=[2, 1]), dict(nx=1024, ny=256, K=4, schedule="edge", runs=[9, 8], grid=[1, 2], ghost="0"),
+        dict(nx=1024, ny=512, K=0, schedule="", runs=[20, 11], grid=[1, 2], scatter=True), dict(nx=1024, ny=512, K=0, schedule="edge", runs=[9, 12], grid=[1, 2])],
     3: [dict(nx=256, ny=200, K=2, schedule="edge", runs=[20, 11]), dict(nx=256, ny=200, K=4, schedule="edge", runs=[20, 21], ghost="12"), dict(nx=256, ny=200, K=3, schedule="serial", runs=[31], scatter=True),
         dict(nx=1000, ny=400, K=0, schedule="edge", runs=[5, 5, 5], walls=True),
         dict(nx=772, ny=96, K=0, schedule="", runs=[13, 8], grid=[3, 1], scatter=True)],        # column blocks of 258, 258, 256
