@@ -38,7 +38,7 @@ namespace {
 #endif
 constexpr int kMTX = 64, kMTXNarrow = 32, kMTY = LBM_MTY, kMTY4 = LBM_MTY4, kMTY4Tall = LBM_MTY4T, kMLanes = LBM_MLANES, kMLanes4Tall = LBM_MLANES4T,
               kMaxMultiSteps = 4,
-              kMaxGhost = 16,      // most ghost rows a K-step partition keeps per side: the steps of a group of launches between two halo exchanges
+              kMaxGhost = 32,      // most ghost rows / columns a K-step partition keeps per side: the steps of a group of launches between two halo exchanges (32: column blocks)
               kMaxGroup = 8;       // most launches of such a group
 constexpr int kMinMultiTY = kMTY < kMTY4 ? (kMTY < kMTY4Tall ? kMTY : kMTY4Tall) : (kMTY4 < kMTY4Tall ? kMTY4 : kMTY4Tall);
 // Geometry of a launch: tile width, and by steps per launch tile height and block size.

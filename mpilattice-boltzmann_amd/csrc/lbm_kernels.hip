@@ -1008,7 +1008,13 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
   out->x0 = xdis[out->rx]; out->nx_local = nxl[out->rx];
   out->y0 = ydis[out->ry]; out->ny_local = nyl[out->ry];
   const int k = macro_k_for(static_cast<size_t>(chi) * rhi);
-  const int ghost = macro_ghost_for(k, chi, rlo, rhi);
+  int ghost = macro_ghost_for(k, chi, rlo, rhi);
+  // Column blocks (py = 1) below the edge-stream size: 32 ghost columns, eight launches per exchange.  Their ghost depth costs columns only (no
+  // launch advances ghost rows), and their launches are bound by latency, not by the cells they compute: us/step for 16 / 24 / 32 ghost columns
+  // 2048 x 512 8.05 / 8.00 / 7.85, 4096 x 256 8.40 / 8.21 / 8.18, 8192 x 128 8.77 / 8.58 / 8.46, 512 x 512 4.06 / 3.96 / 3.87, 256 x 512 3.32 / 3.20 / 3.14
+  // (profiles/r04/ab_column_block_ghost_depth.txt).  LBM_TUNE_MACRO_GHOST still overrides.
+  if (k > 0 && py == 1 && clo >= 256 && !tune_env("LBM_TUNE_TILE_GHOST_ROWS", 0) && static_cast<size_t>(chi) * rhi < (size_t(1) << 21) && tune_env("LBM_TUNE_MACRO_GHOST", -1) < 0)   // (blocks of >= 256 columns: the measured range)
+    ghost = std::max(ghost, std::min(32 / k * k, static_cast<int>(kMaxGhost)));
   int ghost_x = (ghost + 1) & ~1;
   ghost_x = std::min(std::max(tune_env("LBM_TUNE_TILE_GHOST_X", ghost_x) & ~1, ghost_x), kMaxGhost);
   // every rank's storage rows (owned + ghost columns) must be ones the K-step kernels take, and its own columns at least the ghost
@@ -1061,7 +1067,9 @@ int lbm_choose_rank_grid(const lbm_params* p, int nranks, unsigned flags, int* p
     lbm_tile_layout t;
     if (lbm_tile_layout_of(p, qx, nranks / qx, nranks - 1, flags, &t)) continue;      // a rank would fall out of K-step mode: not a candidate
     // (the last rank holds the smallest column block and, by the reference's rule, not the largest row block)
-    const double cost = t.ghost_y > 0 ? 0.75 * t.ghost_y / t.ny_local + 2.0 * t.ghost_x / t.nx_local + 0.05 + thin(t.ny_local) : 2.0 * t.ghost_x / t.nx_local + 0.02;
+    // (a column block's 32 ghost columns count as 16 here: the rule was measured at 16, and the deeper halo only made the column blocks faster)
+    const double cost = t.ghost_y > 0 ? 0.75 * t.ghost_y / t.ny_local + 2.0 * t.ghost_x / t.nx_local + 0.05 + thin(t.ny_local)
+                                      : 2.0 * std::min(t.ghost_x, 16) / t.nx_local + 0.02;
     if (cost < best) { best = cost; *px = qx; *py = nranks / qx; }
   }
   (void)lbm_last_error();

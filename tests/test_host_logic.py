@@ -75,7 +75,7 @@ int main(void)
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 0 and r.stdout == "4 3 3 | 159 31 0\n8 x 1 | 14336 2048 0 512 | 16 16 0\n", (r.returncode, r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout == "4 3 3 | 159 31 0\n8 x 1 | 14336 2048 0 512 | 32 32 0\n", (r.returncode, r.stdout, r.stderr)
 
 
 def test_rccl_library_exports_every_declared_symbol(lbm):
@@ -686,10 +686,14 @@ def test_tile_layout_is_one_decision_for_all_ranks(lbm, monkeypatch):
         assert np.all(cover == 1)
         assert len({(l["macro_k"], l["ghost"], l["ghost_x"], l["group"]) for l in lays}) == 1
         l = lays[0]
-        assert l["macro_k"] == 4 and l["ghost_x"] == (l["ghost"] + 1) // 2 * 2 and l["ghost"] <= 16
-        # as a row partition of the same cells: 8 ghost rows for ranks of >= 2 M cells, else as deep as the rows carry
+        assert l["macro_k"] == 4 and l["ghost_x"] == (l["ghost"] + 1) // 2 * 2 and l["ghost"] <= 32
+        # as a row partition of the same cells: 8 ghost rows for ranks of >= 2 M cells, else as deep as the rows carry — and 32 ghost COLUMNS
+        # (eight launches per exchange) for column blocks below 2 M cells, which keep no ghost rows at all
         big = max(x["nx_local"] for x in lays) * max(nyl) >= 1 << 21
-        assert l["ghost"] == (8 if big or 64 <= min(nyl) < 128 else 16 if min(nyl) >= 128 else 4)
+        if py == 1 and not big and min(x["nx_local"] for x in lays) >= 256:
+            assert (l["ghost"], l["ghost_x"], l["ghost_y"], l["group"]) == (32, 32, 0, 8)
+        else:
+            assert l["ghost"] == (8 if big or 64 <= min(nyl) < 128 else 16 if min(nyl) >= 128 else 4) and l["ghost_y"] == (0 if py == 1 else l["ghost"])
     monkeypatch.setenv("LBM_TUNE_MACRO_GHOST", "7")
     assert {(l["ghost"], l["ghost_x"], l["group"]) for l in (lbm.tile_layout(lbm.Params(640, 300, 1, 1, 0.1, 0.005, 1.85), 2, 3, r) for r in range(6))} == {(7, 8, 1)}
     monkeypatch.delenv("LBM_TUNE_MACRO_GHOST")
