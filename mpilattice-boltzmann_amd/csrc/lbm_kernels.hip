@@ -628,12 +628,19 @@ static int macro_k_for(size_t max_cells)
 // One answer for all ranks: from nx and the smallest / largest row count of the run.  LBM_TUNE_MACRO_GHOST overrides (0 or anything
 // below K: K rows, one launch per exchange).  The exchange moves the rows the NEXT group needs (peer-to-peer loop) or all `ghost`
 // rows (RCCL loop).
-static int macro_ghost_for(int k, int nx, int rows_min, int rows_max)
+static int macro_ghost_for(int k, int nx, int rows_min, int rows_max, bool row_blocks = true)
 {
   if (k <= 0) return 0;
   const int classic = k == 3 ? 4 : k, two = k == 3 ? 8 : 2 * k;
   int by_size = two;
   if (static_cast<size_t>(nx) * rows_max < (size_t(1) << 21)) by_size = rows_min >= 128 ? std::max(16 / k * k, two) : rows_min >= 64 ? two : classic;
+  // ... and deeper still for the smallest ranks (round 4, last: kMaxGhost 16 -> 32), whose launches are bound by latency, not by the rows they
+  // compute: us/step for 16 / 24 / 32 ghost rows — 1024 x 128 rows 3.30 / 3.14 / 3.10, 1024 x 256 3.97 / 3.82 / 3.76, 512 x 512 3.86 / 3.70 / 3.63,
+  // 2048 x 256 5.50 / 5.40 / 5.33; not for wider or larger ones: 4096 x 128 6.03 / 6.18 / 6.22, 8192 x 128 10.2 / 10.5 / 10.6, 2048 x 512 7.75 / 7.70 / 7.97,
+  // 1024 x 1024 7.4 / 7.3 / 7.4, and 1024 x 192 3.40 / 3.43 / 3.55 (profiles/r04/ab_row_block_ghost_depth.txt): 24 rows from 128 rows per rank, 32 from 256,
+  // for ranks of at most 2^19 cells in rows of at most 2048 cells
+  if (row_blocks && nx <= 2048 && static_cast<size_t>(nx) * rows_max <= (size_t(1) << 19) && rows_min >= 128)     // (tile ranks: lbm_tile_layout_of has its own rule)
+    by_size = std::max(by_size, std::min((rows_min >= 256 ? 32 : 24) / k * k, static_cast<int>(kMaxGhost)));
   return std::min(std::max(tune_env("LBM_TUNE_MACRO_GHOST", by_size), k), kMaxGhost);
 }
 
@@ -1008,7 +1015,7 @@ int lbm_tile_layout_of(const lbm_params* p, int px, int py, int rank, unsigned f
   out->x0 = xdis[out->rx]; out->nx_local = nxl[out->rx];
   out->y0 = ydis[out->ry]; out->ny_local = nyl[out->ry];
   const int k = macro_k_for(static_cast<size_t>(chi) * rhi);
-  int ghost = macro_ghost_for(k, chi, rlo, rhi);
+  int ghost = macro_ghost_for(k, chi, rlo, rhi, /*row_blocks=*/false);
   // Column blocks (py = 1) below the edge-stream size: 32 ghost columns, eight launches per exchange.  Their ghost depth costs columns only (no
   // launch advances ghost rows), and their launches are bound by latency, not by the cells they compute: us/step for 16 / 24 / 32 ghost columns
   // 2048 x 512 8.05 / 8.00 / 7.85, 4096 x 256 8.40 / 8.21 / 8.18, 8192 x 128 8.77 / 8.58 / 8.46, 512 x 512 4.06 / 3.96 / 3.87, 256 x 512 3.32 / 3.20 / 3.14
